@@ -1,0 +1,331 @@
+"""CPU oracle for the DiffusionNAG reverse-diffusion sampling hot path.
+
+TEST INFRASTRUCTURE ONLY.  This file is a functional, PyTorch-CPU (fp32) restatement
+of the reference algorithm; only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product path
+(``diffusionnag_amd``) never does: it calls the HIP library through the C ABI and
+fails loudly when that library is missing.
+
+Pinning: the reference has no tests or golden vectors, so the
+oracle is pinned against outputs of the reference itself, captured in this
+container by ``tests/golden/make_golden.py`` (which imports
+``/root/reference/NAS-Bench-201``) and committed as ``tests/golden/*.npz``;
+``tests/test_oracle_golden.py`` checks every function below against them.
+
+Every function cites the reference lines it restates (paths relative to
+``/root/reference/NAS-Bench-201/``).  Weights are passed as plain ``state_dict``
+mappings (reference parameter names), no ``nn.Module`` is involved.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# masks and scalers
+# ----------------------------------------------------------------------------------------------
+
+def nb201_adj() -> Tensor:
+    """Fixed NAS-Bench-201 cell adjacency, datasets_nas.py:182-194."""
+    rows = ["01110000", "00001100", "00000010", "00000001",
+            "00000010", "00000001", "00000001", "00000000"]
+    return torch.tensor([[float(c) for c in r] for r in rows])
+
+
+def floyed(adj: Tensor) -> Tensor:
+    """Reachability closure, utils.py:123-139 (the branch taken for ``algo='floyed'``)."""
+    r = adj.clone()
+    n = r.shape[0]
+    for k in range(n):
+        for i in range(n):
+            for j in range(n):
+                if r[i, k] > 0 and r[k, j] > 0:
+                    r[i, j] = 1.0
+    return r
+
+
+def aug_mask(adj: Tensor, algo: str = "floyed") -> Tensor:
+    """utils.py:142-156: only the literal string 'floyed' closes the mask; anything else
+    (including the configs' 'floyd') returns the raw adjacency."""
+    if adj.dim() == 3:
+        adj = adj[0]
+    return floyed(adj) if algo == "floyed" else adj.clone()
+
+
+def inverse_scaler(x: Tensor) -> Tensor:
+    """datasets_nas.py:21-28 with ``data.centered=True``."""
+    return (x + 1.0) / 2.0
+
+
+def quantize(x: Tensor) -> Tensor:
+    """utils.py:244-262: threshold at 0.5 (returned as one tensor instead of a list of arrays)."""
+    return torch.where(x >= 0.5, torch.ones_like(x), torch.zeros_like(x))
+
+
+# ----------------------------------------------------------------------------------------------
+# VPSDE (sde_lib.py:145-211)
+# ----------------------------------------------------------------------------------------------
+
+class VPSDE:
+    """Scalar schedules of the variance-preserving SDE, sde_lib.py:146-162."""
+
+    def __init__(self, beta_min: float = 0.1, beta_max: float = 20.0, N: int = 1000):
+        self.beta_0, self.beta_1, self.N, self.T = beta_min, beta_max, N, 1
+        self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)   # :158
+        self.alphas = 1.0 - self.discrete_betas                               # :159
+
+    def marginal_std(self, t: Tensor) -> Tensor:
+        """sde_lib.py:179-188 (only the std is used while sampling)."""
+        lmc = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        return torch.sqrt(1.0 - torch.exp(2.0 * lmc))
+
+    def timestep_index(self, t: Tensor) -> Tensor:
+        """sde_lib.py:200 / sampling.py:238: truncating float -> int64."""
+        return (t * (self.N - 1) / self.T).long()
+
+    def discretize(self, x: Tensor, t: Tensor):
+        """DDPM discretisation, sde_lib.py:198-211."""
+        k = self.timestep_index(t)
+        beta = self.discrete_betas[k]
+        alpha = self.alphas[k]
+        f = torch.sqrt(alpha)[:, None, None] * x - x
+        G = torch.sqrt(beta)
+        return f, G
+
+
+def timesteps(sde: VPSDE, eps: float) -> Tensor:
+    """sampling.py:437."""
+    return torch.linspace(sde.T, eps, sde.N)
+
+
+# ----------------------------------------------------------------------------------------------
+# CATE score network (models/cate.py:108-164, models/transformer.py)
+# ----------------------------------------------------------------------------------------------
+
+def timestep_embedding(labels: Tensor, dim: int, max_positions: int = 10000) -> Tensor:
+    """cate.py:363-374 / digcn_meta.py:162-173."""
+    half = dim // 2
+    c = math.log(max_positions) / (half - 1)
+    freq = torch.exp(torch.arange(half, dtype=torch.float32) * -c)
+    arg = labels.float()[:, None] * freq[None, :]
+    return torch.cat([torch.sin(arg), torch.cos(arg)], dim=1)
+
+
+def positional_table(max_node: int, d_model: int, stagewise: bool) -> Tensor:
+    """cate.py:231-248 (Cell) and cate.py:211-228 (StageWise: table of max_node/5 rows tiled 5x)."""
+    stages = 5 if stagewise else 1
+    length = int(max_node / stages)
+    enc = torch.zeros(length, d_model)
+    pos = torch.arange(0, length).float().unsqueeze(1)
+    two_i = torch.arange(0, d_model, step=2).float()
+    enc[:, ::2] = torch.sin(pos / (10000 ** (two_i / d_model)))
+    enc[:, 1::2] = torch.cos(pos / (10000 ** (two_i / d_model)))
+    return torch.cat([enc] * stages, dim=0)
+
+
+def _lin(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    return F.linear(x, sd[prefix + ".weight"], sd.get(prefix + ".bias"))
+
+
+def _ln(sd: SD, prefix: str, x: Tensor) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], 1e-5)
+
+
+def time_mlp(sd: SD, labels: Tensor, d_model: int) -> Tensor:
+    """cate.py:155-157: timeEmb2(SiLU(timeEmb1(sincos(labels))))  (config nonlinearity 'swish')."""
+    e = timestep_embedding(labels, d_model)
+    return _lin(sd, "timeEmb2", F.silu(_lin(sd, "timeEmb1", e)))
+
+
+def encoder_stack(sd: SD, prefix: str, emb: Tensor, mask: Tensor, n_layers: int, n_head: int,
+                  record: Optional[dict] = None) -> List[Tensor]:
+    """transformer.py:166-179 (Encoder), :127-136 (EncoderBlock), :69-80, :23-42, :12-20, :97-108."""
+    B, N, d = emb.shape
+    dk = d // n_head
+    x = emb
+    outs = []
+    m4 = mask.unsqueeze(1)                                                      # :36
+    for l in range(n_layers):
+        p = f"{prefix}.layers.{l}"
+        u = _ln(sd, p + ".self_attn.norm", x)                                   # :78
+        q, k, v = [_lin(sd, p + f".self_attn.attn.linears.{j}", u).view(B, -1, n_head, dk).transpose(1, 2)
+                   for j in range(3)]                                           # :39
+        s = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(dk)                # :14
+        s = s.masked_fill(m4 == 0, -1e9)                                        # :16
+        a = F.softmax(s, dim=-1)                                                # :17
+        if record is not None and l == 0:
+            record["attn0"] = a
+        o = torch.matmul(a, v).transpose(1, 2).contiguous().view(B, -1, d)      # :20, :41
+        x = _lin(sd, p + ".self_attn.attn.linears.3", o) + x                    # :42, :80
+        u = _ln(sd, p + ".feed_forward.norm", x)                                # :106
+        x = _lin(sd, p + ".feed_forward.feed_forward.w_2",
+                 F.relu(_lin(sd, p + ".feed_forward.feed_forward.w_1", u))) + x  # :54, :108
+        outs.append(_ln(sd, f"{prefix}.norms.{l}", x))                          # :177
+    return outs
+
+
+def mlp_head(sd: SD, prefix: str, h: Tensor, n_lin: int) -> Tensor:
+    """cate.py:55-73 with activate_func=F.elu."""
+    for j in range(n_lin - 1):
+        h = F.elu(_lin(sd, f"{prefix}.linears.{j}", h))
+    return _lin(sd, f"{prefix}.linears.{n_lin - 1}", h)
+
+
+def cate_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, *, n_layers: int = 12,
+                 n_head: int = 8, stagewise_pos: bool = False, record: Optional[dict] = None) -> Tensor:
+    """CATE.forward, cate.py:145-164 (eval mode: dropouts are identity, models/utils.py:63-65)."""
+    d = sd["opEmb.fc.weight"].shape[0]
+    emb_x = _lin(sd, "opEmb.fc", X) * math.sqrt(d)                              # transformer.py:230
+    emb_x = emb_x + positional_table(X.shape[1], d, stagewise_pos)[: X.shape[1]]  # cate.py:149-151
+    emb = emb_x + time_mlp(sd, time_cond, d).unsqueeze(1)                       # cate.py:155-159
+    hs = encoder_stack(sd, "graph_encoder.encoder_f", emb, maskX, n_layers, n_head, record)
+    h = torch.cat(hs, dim=-1)                                                   # cate.py:85
+    if record is not None:
+        record["concat"] = h
+    return mlp_head(sd, "final", h, 3)                                          # cate.py:162
+
+
+def score_fn(sd: SD, sde: VPSDE, x: Tensor, t: Tensor, maskX: Tensor, **kw) -> Tensor:
+    """models/utils.py:88-104 (continuous=True): labels = 999 t, score = -model/std."""
+    out = cate_forward(sd, x, t * 999, maskX, **kw)
+    std = sde.marginal_std(t)
+    return -out / std[:, None, None]
+
+
+# ----------------------------------------------------------------------------------------------
+# MetaNeuralPredictor surrogate (models/digcn_meta.py) and its guidance gradient
+# ----------------------------------------------------------------------------------------------
+
+def normalize_adj(adj: Tensor) -> Tensor:
+    """digcn_meta.py:12-16."""
+    rowsum = adj.sum(2, keepdim=True).repeat(1, 1, adj.size(-1))
+    return torch.div(adj, rowsum)
+
+
+def _mab(sd: SD, p: str, Q: Tensor, K: Tensor, heads: int) -> Tensor:
+    """set_encoder/setenc_modules.py:23-37 (ln=False)."""
+    Q = _lin(sd, p + ".fc_q", Q)
+    Kp, V = _lin(sd, p + ".fc_k", K), _lin(sd, p + ".fc_v", K)
+    dim_v = Q.shape[-1]
+    split = dim_v // heads
+    Q_ = torch.cat(Q.split(split, 2), 0)
+    K_ = torch.cat(Kp.split(split, 2), 0)
+    V_ = torch.cat(V.split(split, 2), 0)
+    A = torch.softmax(Q_.bmm(K_.transpose(1, 2)) / math.sqrt(dim_v), 2)
+    O = torch.cat((Q_ + A.bmm(V_)).split(Q.size(0), 0), 2)
+    return O + F.relu(_lin(sd, p + ".fc_o", O))
+
+
+def _setpool(sd: SD, p: str, X: Tensor, heads: int) -> Tensor:
+    """set_encoder/setenc_models.py:35-38 for mode='sabPF'."""
+    h = _mab(sd, p + ".enc.0.mab", X, X, heads)
+    h = _mab(sd, p + ".enc.1.mab", h, h, heads)
+    S = sd[p + ".dec.0.S"].repeat(h.size(0), 1, 1)
+    h = _mab(sd, p + ".dec.0.mab", S, h, heads)
+    return _lin(sd, p + ".dec.1", h)
+
+
+def set_encode(sd: SD, task: Tensor, num_sample: int = 20, heads: int = 4) -> Tensor:
+    """digcn_meta.py:131-139 for ONE task ``[num_class*num_sample, 512]`` -> D_mu ``[nz]``.
+    The reference repeats the task B times and recomputes identical rows."""
+    cls_protos = _setpool(sd, "intra_setpool", task.view(-1, num_sample, 512), heads).squeeze(1)
+    return _setpool(sd, "inter_setpool", cls_protos.unsqueeze(0), heads).reshape(-1)
+
+
+def predictor_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, D_mu: Tensor) -> Tensor:
+    """MetaNeuralPredictor.forward with cached D_mu, digcn_meta.py:109-129, :141-159, :39-48."""
+    B, N, _ = X.shape
+    g = sd["fc1.weight"].shape[1]
+    emb_t = _lin(sd, "timeEmb2", F.silu(_lin(sd, "timeEmb1", timestep_embedding(time_cond, g))))  # :116-118
+    adj = normalize_adj(maskX + torch.eye(N))                                   # :120
+    out = X
+    n_gcn = len([k for k in sd if k.startswith("gcn.") and k.endswith("weight1")])
+    for l in range(n_gcn):
+        na = normalize_adj(adj)                                                 # :42
+        o1 = F.relu(torch.matmul(na, torch.matmul(out, sd[f"gcn.{l}.weight1"])))  # :43
+        ina = normalize_adj(adj.transpose(1, 2))                                # :44
+        o2 = F.relu(torch.matmul(ina, torch.matmul(out, sd[f"gcn.{l}.weight2"])))  # :45
+        out = (o1 + o2) / 2                                                     # :46
+    numv = torch.tensor([N] * B)
+    out = torch.div(out.sum(1), numv.unsqueeze(-1).expand(B, g))                # :19-22
+    out = out + emb_t                                                           # :125
+    a_mu = F.linear(out, sd["fc1.weight"])                                      # :126
+    vec = torch.cat([D_mu.reshape(1, -1).expand(B, -1), a_mu], dim=1)           # :142-147
+    return _lin(sd, "pred_fc.2", torch.tanh(_lin(sd, "pred_fc.0", vec)))        # :148
+
+
+def classifier_grad(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tensor, labels: str = "max") -> Tensor:
+    """models/utils.py:130-145 (regress=True): d/dx of +-sum_b f(x_b); logit_fn labels = 999 t (:159)."""
+    with torch.enable_grad():
+        x_in = x.detach().clone().requires_grad_(True)
+        logit = predictor_forward(sd, x_in, t * 999, maskX, D_mu)
+        prob = logit.sum() if labels == "max" else -logit.sum()
+        return torch.autograd.grad(prob, x_in)[0]
+
+
+# ----------------------------------------------------------------------------------------------
+# predictor-corrector loop (sampling.py:203-256, :424-445, :496-577)
+# ----------------------------------------------------------------------------------------------
+
+def pc_sample(score_sd: SD, sde: VPSDE, mask: Tensor, tape: dict, *, eps: float = 1e-3, snr: float = 0.16,
+              n_steps: Optional[int] = None, pred_sd: Optional[SD] = None, D_mu: Optional[Tensor] = None,
+              classifier_scale: float = 0.0, labels: str = "max", record: Optional[list] = None,
+              model_kw: Optional[dict] = None) -> Tensor:
+    """Reverse-diffusion predictor + Langevin corrector with injected noise.
+
+    ``tape`` = {'x0': [B,N,V], 'corrector': [S,B,N,V], 'predictor': [S,B,N,V]} replaces
+    ``prior_sampling`` (sampling.py:436), ``randn_like`` at :247 and at :210, in that order.
+    ``n_steps`` truncates the loop (the time grid is always the full ``linspace(T, eps, sde.N)``).
+    Returns ``inverse_scaler(x_mean_last)`` (sampling.py:445 / :577, noise_removal=True).
+    """
+    kw = model_kw or {}
+    x = tape["x0"].clone()
+    B = x.shape[0]
+    ts = timesteps(sde, eps)
+    maskX = mask.unsqueeze(0).repeat(B, 1, 1)                                   # :438
+    S = sde.N if n_steps is None else n_steps
+
+    def total_grad(x, vec_t):                                                   # :502-505
+        s = score_fn(score_sd, sde, x, vec_t, maskX, **kw)
+        if pred_sd is None:
+            return s, s, None
+        cg = classifier_grad(pred_sd, x, vec_t, maskX, D_mu, labels)
+        return s + classifier_scale * cg, s, cg
+
+    x_mean = x
+    with torch.no_grad():
+        for i in range(S):
+            vec_t = torch.ones(B) * ts[i]                                       # :442
+            rec = {"x_in": x.clone()} if record is not None else None
+            # -- LangevinCorrector.update_fn, sampling.py:232-256
+            k = sde.timestep_index(vec_t)
+            alpha = sde.alphas[k]
+            grad, s1, cg1 = total_grad(x, vec_t)
+            noise = tape["corrector"][i]
+            grad_norm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
+            noise_norm = torch.norm(noise.reshape(B, -1), dim=-1).mean()
+            step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+            x_mean = x + step_size[:, None, None] * grad
+            x = x_mean + torch.sqrt(step_size * 2)[:, None, None] * noise
+            if rec is not None:
+                rec.update(score_c=s1, cgrad_c=cg1, total_c=grad, grad_norm=grad_norm, noise_norm=noise_norm,
+                           step_size=step_size[0].clone(), x_corr=x.clone())
+            # -- ReverseDiffusionPredictor.update_fn, sampling.py:208-213 + sde_lib.py:119-125
+            f, G = sde.discretize(x, vec_t)
+            grad2, s2, cg2 = total_grad(x, vec_t)
+            rev_f = f - G[:, None, None] ** 2 * grad2
+            z = tape["predictor"][i]
+            x_mean = x - rev_f
+            x = x_mean + G[:, None, None] * z
+            if rec is not None:
+                rec.update(score_p=s2, cgrad_p=cg2, total_p=grad2, x_mean=x_mean.clone(), x_pred=x.clone())
+                record.append(rec)
+    return inverse_scaler(x_mean)

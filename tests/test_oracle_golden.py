@@ -1,0 +1,133 @@
+"""Pin the CPU oracle (oracle/dnag_oracle.py) against vectors captured from the reference
+(tests/golden/*.npz, produced by tests/golden/make_golden.py).  Same aten CPU kernels on both
+sides, so the tolerances are tight; they are not zero because the oracle batches/fuses a few
+ops differently (e.g. D_mu computed once instead of B times)."""
+
+import numpy as np
+import pytest
+import torch
+
+from diffusionnag_amd import synthetic
+from diffusionnag_amd.specs import CateDims, PredictorDims
+from oracle import dnag_oracle as O
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol, atol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b)
+    ok = err <= atol + rtol * np.abs(b)
+    assert ok.all(), f"max abs err {err.max():.3e} (ref scale {np.abs(b).max():.3e}), {(~ok).sum()} bad"
+
+
+@pytest.mark.parametrize("mname", ["raw", "closure"])
+def test_cate_forward_nb201(golden, mname):
+    g = golden(f"cate_fwd_nb201_{mname}")
+    sd = synthetic.cate_state_dict(CateDims(), seed=int(g["seed"]), perturb_norms=True)
+    rec = {}
+    X, mask = T(g["X"]), T(g["mask"])
+    out = O.cate_forward(sd, X, T(g["time_cond"]), mask.unsqueeze(0).repeat(X.shape[0], 1, 1), record=rec)
+    close(out, g["out"], 1e-5, 1e-6)
+    close(rec["attn0"], g["attn0"], 1e-5, 1e-7)
+    close(rec["concat"], g["concat"], 1e-5, 1e-5)
+    # a fully masked query row (the sink node, row 7 of the raw adjacency) attends uniformly
+    if mname == "raw":
+        assert np.allclose(g["attn0"][:, :, 7, :], 1.0 / 8.0)
+
+
+def test_cate_forward_ofa(golden):
+    g = golden("cate_fwd_ofa_chain")
+    dims = CateDims(max_node=20, n_vocab=9, stagewise_pos=True)
+    sd = synthetic.cate_state_dict(dims, seed=int(g["seed"]), perturb_norms=True)
+    X, mask = T(g["X"]), T(g["mask"])
+    out = O.cate_forward(sd, X, T(g["time_cond"]), mask.unsqueeze(0).repeat(X.shape[0], 1, 1), stagewise_pos=True)
+    close(out, g["out"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("mname", ["raw", "closure"])
+def test_predictor_and_guidance_gradient(golden, mname):
+    g = golden(f"predictor_nb201_{mname}")
+    sdp = synthetic.predictor_state_dict(PredictorDims(), seed=int(g["seed"]))
+    task = synthetic.synthetic_task(10, 20, seed=int(g["task_seed"]))
+    D_mu = O.set_encode(sdp, task)
+    close(D_mu, g["D_mu"], 1e-5, 1e-6)
+    X, mask = T(g["X"]), T(g["mask"])
+    mB = mask.unsqueeze(0).repeat(X.shape[0], 1, 1)
+    for i, tval in enumerate(g["t"]):
+        t = torch.ones(X.shape[0]) * float(tval)
+        y = O.predictor_forward(sdp, X, t * 999, mB, D_mu)
+        close(y, g["y"][i], 1e-5, 1e-6)
+        gr = O.classifier_grad(sdp, X, t, mB, D_mu, "max")
+        close(gr, g["grad"][i], 1e-4, 1e-8)
+        close(O.classifier_grad(sdp, X, t, mB, D_mu, "min"), -g["grad"][i], 1e-4, 1e-8)
+
+
+def _run(g, guided, record=None, n_steps=None):
+    sd = synthetic.cate_state_dict(CateDims(), seed=int(g["seed"]), preset=str(g["preset"]))
+    sde = O.VPSDE(0.1, float(g["beta_max"]), int(g["sde_N"]))
+    B = int(g["B"])
+    tape = synthetic.noise_tape(int(g["n_run"]), (B, 8, 7), int(g["tape_seed"]))
+    kw = {}
+    if guided:
+        sdp = synthetic.predictor_state_dict(PredictorDims(), seed=1)
+        kw = dict(pred_sd=sdp, D_mu=O.set_encode(sdp, synthetic.synthetic_task(10, 20, seed=2)),
+                  classifier_scale=float(g["classifier_scale"]))
+    return O.pc_sample(sd, sde, T(g["mask"]), tape, eps=float(g["eps"]), snr=float(g["snr"]),
+                       n_steps=int(g["n_run"]) if n_steps is None else n_steps, record=record, **kw)
+
+
+@pytest.mark.parametrize("name,guided", [("pc_uncond_nb201_n1000_first8", False),
+                                         ("pc_guided_nb201_n1000_first8", True)])
+def test_pc_first_steps_random_init(golden, name, guided):
+    g = golden(name)
+    rec = []
+    _run(g, guided, rec)
+    for i, r in enumerate(rec):
+        sc = np.abs(g["x_pred"][i]).max()
+        close(r["score_c"], g["score_c"][i], 2e-4, 2e-4 * np.abs(g["score_c"][i]).max())
+        close(r["x_corr"], g["x_corr"][i], 0, 2e-4 * sc)
+        close(r["x_pred"], g["x_pred"][i], 0, 2e-4 * sc)
+        if guided:
+            close(r["cgrad_c"], g["cgrad_c"][i], 1e-3, 1e-3 * np.abs(g["cgrad_c"][i]).max())
+
+
+@pytest.mark.parametrize("name,guided", [("pc_uncond_nb201_contractive_n100", False),
+                                         ("pc_guided_nb201_contractive_n100", True)])
+def test_pc_full_trajectory_contractive(golden, name, guided):
+    g = golden(name)
+    rec = []
+    final = _run(g, guided, rec)
+    for i in (0, 1, 10, 50, 99):
+        close(rec[i]["x_pred"], g["x_pred"][i], 1e-4, 1e-4)
+        close(rec[i]["score_p"], g["score_p"][i], 1e-4, 1e-4 * np.abs(g["score_p"][i]).max())
+    close(final, g["final"], 1e-4, 1e-4)
+    assert torch.equal(O.quantize(final.clone()), O.quantize(T(g["final"]).clone()))
+
+
+def test_linspace_and_index_edges():
+    sde = O.VPSDE(0.1, 20.0, 1000)
+    ts = O.timesteps(sde, 1e-3)
+    k = sde.timestep_index(ts)
+    assert int(k[0]) == 999 and int(k[-1]) == 0
+    assert (k[:-1] >= k[1:]).all()
+
+
+def test_mask_helpers():
+    adj = O.nb201_adj()
+    assert torch.equal(adj, synthetic.nb201_adjacency())
+    assert torch.equal(O.aug_mask(adj, "floyd"), adj)            # the reference's typo path: raw adjacency
+    cl = O.aug_mask(adj, "floyed")
+    assert torch.equal(cl, synthetic.transitive_closure(adj))
+    assert cl[0, 7] == 1 and cl[0, 0] == 0 and cl.sum() > adj.sum()
+
+
+def test_pc_full_n1000_guided_contractive(golden):
+    """The real schedule length (N=1000, 2000 guided evaluations) end to end at B=4."""
+    g = golden("pc_guided_nb201_contractive_n1000")
+    final = _run(g, True)
+    close(final, g["final"], 2e-4, 2e-4)
+    q, qr = O.quantize(final.clone()), O.quantize(T(g["final"]).clone())
+    assert torch.equal(q, qr)
