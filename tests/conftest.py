@@ -10,6 +10,9 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
 def pytest_configure(config):
+    # The fixtures are tiny (B <= 8): intra-op threading only adds contention on small hosts.
+    import torch
+    torch.set_num_threads(1)
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
