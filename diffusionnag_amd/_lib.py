@@ -1,0 +1,142 @@
+"""ctypes binding of ``libdnag.so`` (C ABI declared in ``include/dnag.h``).
+
+There is no CPU fallback: if the library has not been built (``python __graft_entry__.py`` or
+``make -C diffusionnag_amd/csrc``) every product call raises.  PyTorch is used only for device
+memory and streams; every pointer handed to the library comes from ``Tensor.data_ptr()``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdnag.so")
+
+SCHED_COLS = 8
+SCHED_LABEL, SCHED_STD, SCHED_ALPHA, SCHED_SQRTA, SCHED_G, SCHED_G2, SCHED_T = range(7)
+
+# every symbol include/dnag.h declares (tests check that the built library exports them all)
+EXPORTS = (
+    "dnag_abi_version", "dnag_last_error",
+    "dnag_cate_state_floats", "dnag_cate_table_floats", "dnag_cate_packed_floats", "dnag_cate_pack",
+    "dnag_pred_state_floats", "dnag_pred_table_floats", "dnag_pred_packed_floats", "dnag_pred_pack",
+    "dnag_workspace_bytes", "dnag_cate_forward", "dnag_pred_forward_grad", "dnag_pc_sample",
+    "dnag_quantize", "dnag_timing_begin", "dnag_timing_read", "dnag_timing_end",
+)
+
+
+class CateDimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("max_node", "n_vocab", "d_model", "n_head", "d_ff", "n_layers", "stagewise_pos")]
+
+
+class PredDimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("max_node", "n_vocab", "gcn_hidden", "gcn_layers", "linear_hidden", "hs", "nz")]
+
+
+_fp = C.c_void_p   # float* (device or host address)
+
+
+class PcArgsC(C.Structure):
+    _fields_ = [
+        ("cate_dims", C.POINTER(CateDimsC)), ("cate_packed", _fp),
+        ("pred_dims", C.POINTER(PredDimsC)), ("pred_packed", _fp), ("d_mu", _fp),
+        ("classifier_scale", C.c_float), ("label_sign", C.c_float),
+        ("batch", C.c_int32), ("mask", _fp), ("sched", _fp), ("n_steps", C.c_int32),
+        ("snr", C.c_float), ("corrector", C.c_int32),
+        ("x0", _fp), ("noise_corr", _fp), ("noise_pred", _fp),
+        ("seed", C.c_uint64), ("stream_offset", C.c_uint64),
+        ("x_out", _fp), ("x_last", _fp), ("x_mean_last", _fp),
+        ("rec_score_c", _fp), ("rec_total_c", _fp), ("rec_x_corr", _fp), ("rec_score_p", _fp),
+        ("rec_total_p", _fp), ("rec_x_mean", _fp), ("rec_x_pred", _fp),
+        ("rec_cgrad_c", _fp), ("rec_cgrad_p", _fp), ("rec_step_size", _fp),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library (once).  Raises with build instructions when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP library is not built.  Run `python __graft_entry__.py` "
+            "(or `make -C diffusionnag_amd/csrc`) first; diffusionnag_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    sz, i32, vp = C.c_size_t, C.c_int, C.c_void_p
+    lib.dnag_abi_version.restype = i32
+    lib.dnag_last_error.restype = C.c_char_p
+    for n in ("dnag_cate_state_floats", "dnag_cate_table_floats", "dnag_cate_packed_floats"):
+        getattr(lib, n).restype = sz
+        getattr(lib, n).argtypes = [C.POINTER(CateDimsC)]
+    for n in ("dnag_pred_state_floats", "dnag_pred_table_floats", "dnag_pred_packed_floats"):
+        getattr(lib, n).restype = sz
+        getattr(lib, n).argtypes = [C.POINTER(PredDimsC)]
+    lib.dnag_cate_pack.restype = i32
+    lib.dnag_cate_pack.argtypes = [C.POINTER(CateDimsC), vp, vp, vp]
+    lib.dnag_pred_pack.restype = i32
+    lib.dnag_pred_pack.argtypes = [C.POINTER(PredDimsC), vp, vp, vp]
+    lib.dnag_workspace_bytes.restype = sz
+    lib.dnag_workspace_bytes.argtypes = [C.POINTER(CateDimsC), C.POINTER(PredDimsC), i32, i32]
+    lib.dnag_cate_forward.restype = i32
+    lib.dnag_cate_forward.argtypes = [C.POINTER(CateDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, sz, vp]
+    lib.dnag_pred_forward_grad.restype = i32
+    lib.dnag_pred_forward_grad.argtypes = [C.POINTER(PredDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, sz, vp]
+    lib.dnag_pc_sample.restype = i32
+    lib.dnag_pc_sample.argtypes = [C.POINTER(PcArgsC)]
+    lib.dnag_quantize.restype = i32
+    lib.dnag_quantize.argtypes = [vp, vp, sz, vp]
+    lib.dnag_timing_begin.restype = i32
+    lib.dnag_timing_begin.argtypes = [i32, i32]
+    lib.dnag_timing_read.restype = i32
+    lib.dnag_timing_read.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.dnag_timing_end.restype = i32
+    lib.dnag_timing_end.argtypes = []
+    if lib.dnag_abi_version() != 1:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.dnag_abi_version()} != 1; rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    """Turn a negative return code into RuntimeError carrying dnag_last_error() (no exceptions cross the ABI)."""
+    if rc != 0:
+        msg = load().dnag_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Address of a contiguous fp32 tensor, or NULL."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("dnag buffers must be contiguous float32 tensors")
+    return t.data_ptr()
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    """All tensors must live on one HIP device; the product path has no CPU implementation."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("diffusionnag_amd runs on an MI355X only: got a CPU tensor (no CPU fallback exists)")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} and {t.device}")
+    return dev
+
+
+def current_stream(dev: torch.device) -> int:
+    return torch.cuda.current_stream(dev).cuda_stream

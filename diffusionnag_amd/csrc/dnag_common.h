@@ -1,0 +1,163 @@
+// Shared declarations of the dnag HIP library: packed-weight layouts and device helpers.
+// gfx950 (CDNA4) only: wave = 64 lanes, fp32-input MFMA (v_mfma_f32_32x32x2_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/dnag.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // native 16-byte vector (HIP float4 is a struct that SROA may leave in scratch)
+
+#define DNAG_D 64          // d_model of every transformer on the path (configs/tr_scorenet.py:96)
+
+static inline __host__ __device__ size_t align4(size_t x) { return (x + 3) & ~(size_t)3; }
+
+// ---------------------------------------------------------------------------------------------
+// Kernel layout of the CATE score network (offsets in floats into the packed blob).
+// Per layer (LayerNorm affine of self_attn.norm / feed_forward.norm folded into Wqkv / W1):
+//   Wqkv'[3d][d] bqkv'[3d] Wo[d][d] bo[d] W1'[dff][d] b1'[dff] W2[d][dff] b2[d] on_g[d] on_b[d]
+// ---------------------------------------------------------------------------------------------
+struct CateLayout {
+    int N, V, d, H, dff, L;
+    size_t emb_w, emb_b;          // opEmb.fc [d][V], [d]
+    size_t t1_w, t1_b, t2_w, t2_b;  // timeEmb1 [4d][d],[4d]; timeEmb2 [d][4d],[d]
+    size_t layer0, layer_stride;
+    size_t l_wqkv, l_bqkv, l_wo, l_bo, l_w1, l_b1, l_w2, l_b2, l_ong, l_onb;  // relative to a layer base
+    size_t f0_w, f0_b, f1_w, f1_b, f2_w, f2_b;  // final.linears.{0,1,2}
+    size_t pe, freq;              // [N][d], [d/2]
+    size_t total;
+    int F, Hd;                    // F = L*d (concat width), Hd = 2F (head hidden)
+};
+
+static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c) {
+    CateLayout y;
+    y.N = c.max_node; y.V = c.n_vocab; y.d = c.d_model; y.H = c.n_head; y.dff = c.d_ff; y.L = c.n_layers;
+    const size_t d = y.d, dff = y.dff, V = y.V;
+    y.F = y.L * y.d; y.Hd = 2 * y.F;
+    size_t o = 0;
+    y.emb_w = o; o += align4(d * V);
+    y.emb_b = o; o += d;
+    y.t1_w = o; o += 4 * d * d;
+    y.t1_b = o; o += 4 * d;
+    y.t2_w = o; o += 4 * d * d;
+    y.t2_b = o; o += d;
+    y.layer0 = o;
+    size_t l = 0;
+    y.l_wqkv = l; l += 3 * d * d;
+    y.l_bqkv = l; l += 3 * d;
+    y.l_wo = l; l += d * d;
+    y.l_bo = l; l += d;
+    y.l_w1 = l; l += dff * d;
+    y.l_b1 = l; l += align4(dff);
+    y.l_w2 = l; l += d * dff;
+    y.l_b2 = l; l += d;
+    y.l_ong = l; l += d;
+    y.l_onb = l; l += d;
+    y.layer_stride = l;
+    o += l * y.L;
+    const size_t F = y.F, Hd = y.Hd;
+    y.f0_w = o; o += Hd * F;
+    y.f0_b = o; o += Hd;
+    y.f1_w = o; o += Hd * Hd;
+    y.f1_b = o; o += Hd;
+    y.f2_w = o; o += align4(V * Hd);
+    y.f2_b = o; o += align4(V);
+    y.pe = o; o += align4((size_t)y.N * d);
+    y.freq = o; o += align4(d / 2);
+    y.total = o;
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel layout of the MetaNeuralPredictor surrogate.
+//   gcn l: W1 [in][g], W2 [in][g] (reference layout, used by the backward pass as B[k=out][col=in]^T,
+//          i.e. row `in` is K-contiguous over `out`) and W1t [g][in], W2t [g][in] (forward pass).
+// ---------------------------------------------------------------------------------------------
+#define DNAG_MAX_GCN 8
+struct PredLayout {
+    int N, V, g, L, lh, hs, nz;
+    size_t w1[DNAG_MAX_GCN], w2[DNAG_MAX_GCN], w1t[DNAG_MAX_GCN], w2t[DNAG_MAX_GCN];
+    size_t fc1, fc1t;             // fc1 [lh][g], fc1t [g][lh]
+    size_t t1_w, t1_b, t2_w, t2_b;  // [4g][g],[4g],[g][4g],[g]
+    size_t p0_w, p0_b;            // pred_fc.0 [hs][nz+lh], [hs]
+    size_t p0_at;                 // transposed arch part [lh][hs]
+    size_t p2_w, p2_b;            // pred_fc.2 [hs], [1]
+    size_t freq;                  // [g/2]
+    size_t total;
+};
+
+static inline __host__ __device__ PredLayout pred_layout(const dnag_pred_dims &c) {
+    PredLayout y;
+    y.N = c.max_node; y.V = c.n_vocab; y.g = c.gcn_hidden; y.L = c.gcn_layers; y.lh = c.linear_hidden;
+    y.hs = c.hs; y.nz = c.nz;
+    const size_t g = y.g, lh = y.lh, hs = y.hs, nz = y.nz;
+    size_t o = 0;
+    for (int l = 0; l < y.L && l < DNAG_MAX_GCN; ++l) {
+        const size_t in = l == 0 ? (size_t)y.V : g;
+        y.w1[l] = o; o += align4(in * g);
+        y.w2[l] = o; o += align4(in * g);
+        y.w1t[l] = o; o += align4(in * g);
+        y.w2t[l] = o; o += align4(in * g);
+    }
+    y.fc1 = o; o += lh * g;
+    y.fc1t = o; o += lh * g;
+    y.t1_w = o; o += 4 * g * g;
+    y.t1_b = o; o += 4 * g;
+    y.t2_w = o; o += 4 * g * g;
+    y.t2_b = o; o += g;
+    y.p0_w = o; o += align4(hs * (nz + lh));
+    y.p0_b = o; o += align4(hs);
+    y.p0_at = o; o += align4(lh * hs);
+    y.p2_w = o; o += align4(hs);
+    y.p2_b = o; o += 4;
+    y.freq = o; o += align4(g / 2);
+    y.total = o;
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+// D[32x32] += A[32x2] * B[2x32].  Lane l supplies A[l&31][l>>5] and B[l>>5][l&31]; lane l holds
+// D[(reg&3) + 8*(reg>>2) + 4*(l>>5)][l&31] in acc[reg]  (cdna_hip_programming.md section 3).
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// Philox4x32-10 (Salmon et al. 2011); returns 4 uint32.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// One standard normal for global element index `e` of draw `draw` (draw = 0: prior, 1 + 2*step:
+// corrector noise of that step, 2 + 2*step: predictor noise).  Four consecutive elements share one
+// Philox block; Box-Muller on (out0,out1) and (out2,out3).
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t e, uint32_t draw) {
+    uint32_t r[4];
+    const uint64_t blk = e >> 2;
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), draw, 0x5eedu, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    const int c = (int)(e & 3);
+    const uint32_t ua = (c < 2) ? r[0] : r[2], ub = (c < 2) ? r[1] : r[3];
+    const float u1 = ((float)ua + 1.0f) * 2.3283064365386963e-10f;   // (0, 1]
+    const float u2 = (float)ub * 2.3283064365386963e-10f;            // [0, 1]
+    const float rad = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.283185307179586f * u2;
+    return (c & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+#endif

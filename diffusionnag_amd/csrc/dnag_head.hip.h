@@ -1,0 +1,352 @@
+// Head MLP of the CATE score network (models/cate.py:55-73 built at :125-126, ~90 % of the path's
+// FLOPs) and the fused exit of a score evaluation.  Included by dnag_lib.hip.
+//   gemm_bias_elu_kernel : C = elu(A W^T + b), fp32 MFMA, 128x128x32 tiles          (final.linears.0/1)
+//   head_out_kernel      : out = H2 W3^T + b3 (V = 7/9 columns, HBM-bound) fused with
+//                          score scaling (models/utils.py:103), guidance sum (sampling.py:502-505),
+//                          Langevin norm partials (sampling.py:249-250) or the reverse-diffusion
+//                          predictor update (sampling.py:208-213, sde_lib.py:119-125, :198-211).
+#pragma once
+#include "dnag_common.h"
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 32
+#define GEMM_LS (GEMM_BK + 4)   // LDS row stride (floats): 36 -> conflict-free ds_read_b128
+
+// A [M][K] row-major (M % 128 == 0), W [Nout][K] row-major (Nout % 128 == 0), K % 32 == 0.
+template <bool ELU, int TAG>
+__global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                               const float *__restrict__ bias, float *__restrict__ C,
+                                                               int M, int Nout, int K) {
+    __shared__ __attribute__((aligned(16))) float As[2][GEMM_BM * GEMM_LS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GEMM_BN * GEMM_LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: blocks that share an XCD (same blockIdx % 8) walk a contiguous
+    // run of tiles, N fastest, so an A row panel is reused out of that XCD's L2.
+    const int nbn = Nout / GEMM_BN;
+    const int nwg = gridDim.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+    const int wg = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int tm = wg / nbn, tn = wg - tm * nbn;
+
+    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    const float *Ag = A + (size_t)(tm * GEMM_BM + lrow) * K + lk;
+    const float *Wg = W + (size_t)(tn * GEMM_BN + lrow) * K + lk;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    v4f ra[4], rb[4];
+    const int KT = K / GEMM_BK;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(32 * p) * K);
+        rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(32 * p) * K);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        *reinterpret_cast<v4f *>(&As[0][(lrow + 32 * p) * GEMM_LS + lk]) = ra[p];
+        *reinterpret_cast<v4f *>(&Bs[0][(lrow + 32 * p) * GEMM_LS + lk]) = rb[p];
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(32 * p) * K + (kt + 1) * GEMM_BK);
+                rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(32 * p) * K + (kt + 1) * GEMM_BK);
+            }
+        }
+        const float *as = &As[cur][(wm * 64 + r) * GEMM_LS + 4 * h];
+        const float *bs = &Bs[cur][(wn * 64 + r) * GEMM_LS + 4 * h];
+#pragma unroll
+        for (int kc = 0; kc < GEMM_BK / 8; ++kc) {
+            const v4f a0 = *reinterpret_cast<const v4f *>(as + kc * 8);
+            const v4f a1 = *reinterpret_cast<const v4f *>(as + 32 * GEMM_LS + kc * 8);
+            const v4f b0 = *reinterpret_cast<const v4f *>(bs + kc * 8);
+            const v4f b1 = *reinterpret_cast<const v4f *>(bs + 32 * GEMM_LS + kc * 8);
+            acc[0][0] = mfma32(a0.x, b0.x, acc[0][0]); acc[0][1] = mfma32(a0.x, b1.x, acc[0][1]);
+            acc[1][0] = mfma32(a1.x, b0.x, acc[1][0]); acc[1][1] = mfma32(a1.x, b1.x, acc[1][1]);
+            acc[0][0] = mfma32(a0.y, b0.y, acc[0][0]); acc[0][1] = mfma32(a0.y, b1.y, acc[0][1]);
+            acc[1][0] = mfma32(a1.y, b0.y, acc[1][0]); acc[1][1] = mfma32(a1.y, b1.y, acc[1][1]);
+            acc[0][0] = mfma32(a0.z, b0.z, acc[0][0]); acc[0][1] = mfma32(a0.z, b1.z, acc[0][1]);
+            acc[1][0] = mfma32(a1.z, b0.z, acc[1][0]); acc[1][1] = mfma32(a1.z, b1.z, acc[1][1]);
+            acc[0][0] = mfma32(a0.w, b0.w, acc[0][0]); acc[0][1] = mfma32(a0.w, b1.w, acc[0][1]);
+            acc[1][0] = mfma32(a1.w, b0.w, acc[1][0]); acc[1][1] = mfma32(a1.w, b1.w, acc[1][1]);
+        }
+        if (kt + 1 < KT) {
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<v4f *>(&As[nxt][(lrow + 32 * p) * GEMM_LS + lk]) = ra[p];
+                *reinterpret_cast<v4f *>(&Bs[nxt][(lrow + 32 * p) * GEMM_LS + lk]) = rb[p];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: bias + ELU, 128-byte row segments per half-wave
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = tn * GEMM_BN + wn * 64 + j * 32 + r;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row0 = tm * GEMM_BM + wm * 64 + i * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv;
+                if (ELU) v = elu1(v);
+                C[(size_t)(row0 + acc_row(e, h)) * Nout + col] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exit of one score evaluation.
+// ---------------------------------------------------------------------------------------------
+enum { EXIT_FORWARD = 0, EXIT_CORRECTOR = 1, EXIT_PREDICTOR = 2 };
+
+struct ExitArgs {
+    int mode;
+    int batch;
+    // score scaling / guidance
+    float std;                    // marginal std at t          (EXIT_CORRECTOR / EXIT_PREDICTOR)
+    float cscale;                 // classifier_scale * label sign; cgrad may be null
+    const float *cgrad;           // [batch][N][V]
+    // EXIT_FORWARD
+    float *out;                   // [batch][N][V] raw model output
+    // EXIT_CORRECTOR
+    float *gbuf;                  // [batch][N][V] total gradient
+    float *partials;              // [2][gridDim.x]: per-block sums of ||grad_b||, ||noise_b||
+    // EXIT_PREDICTOR
+    float *x;                     // state, updated in place
+    float *x_mean;                // [batch][N][V]
+    float sqrt_alpha, G, G2;
+    // noise of this exit (corrector: only its norm is needed here)
+    const float *noise;           // tape slice [batch][N][V] or null -> Philox
+    uint64_t seed, stream_offset;
+    uint32_t draw;
+    // optional records
+    float *rec_score, *rec_total, *rec_a, *rec_b;   // predictor: rec_a = x_mean, rec_b = x_pred
+};
+
+// H2 [rows_pad][K]; W3 [V][K]; b3 [V].  One block = GF graphs = GF*N <= 64 rows.
+template <int N, int V, int GF>
+__global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__ H2, const float *__restrict__ W3,
+                                                       const float *__restrict__ b3, int K, ExitArgs a) {
+    constexpr int R = GF * N;
+    static_assert(R <= 64, "rows per block");
+    constexpr int AS = 68;
+    __shared__ __attribute__((aligned(16))) float As[64 * AS];
+    __shared__ __attribute__((aligned(16))) float Ws[V * 64];
+    __shared__ float red[4][64][V];
+    __shared__ float tot[64 * V];
+    __shared__ float nz[64 * V];
+    __shared__ float gn[GF], nn[GF];
+
+    const int tid = threadIdx.x;
+    const int row0 = blockIdx.x * R;
+    const int r = tid & 63, kq = tid >> 6;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+
+    const int lrow = tid >> 4, lk = (tid & 15) * 4;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int rr = lrow + 16 * p;
+            v4f v4 = v4f{0.f, 0.f, 0.f, 0.f};
+            if (rr < R && (blockIdx.x * GF + rr / N) < a.batch) v4 = *reinterpret_cast<const v4f *>(H2 + (size_t)(row0 + rr) * K + k0 + lk);
+            *reinterpret_cast<v4f *>(&As[rr * AS + lk]) = v4;
+        }
+        for (int i = tid; i < V * 16; i += 256) {
+            const int v = i >> 4, kk = (i & 15) * 4;
+            *reinterpret_cast<v4f *>(&Ws[v * 64 + kk]) = *reinterpret_cast<const v4f *>(W3 + (size_t)v * K + k0 + kk);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const v4f a4 = *reinterpret_cast<const v4f *>(&As[r * AS + kq * 16 + 4 * i]);
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                const v4f w4 = *reinterpret_cast<const v4f *>(&Ws[v * 64 + kq * 16 + 4 * i]);
+                acc[v] = fmaf(a4.x, w4.x, acc[v]); acc[v] = fmaf(a4.y, w4.y, acc[v]);
+                acc[v] = fmaf(a4.z, w4.z, acc[v]); acc[v] = fmaf(a4.w, w4.w, acc[v]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) red[kq][r][v] = acc[v];
+    __syncthreads();
+
+    // one thread per (row, v) element of this block
+    for (int i = tid; i < 64 * V; i += 256) {
+        const int rr = i / V, v = i - rr * V;
+        const int g = rr / N;
+        const bool valid = rr < R && (blockIdx.x * GF + g) < a.batch;
+        float total = 0.f, noise = 0.f;
+        if (valid) {
+            const float val = ((red[0][rr][v] + red[1][rr][v]) + (red[2][rr][v] + red[3][rr][v])) + b3[v];
+            const size_t e = (size_t)(row0 + rr) * V + v;
+            if (a.mode == EXIT_FORWARD) {
+                a.out[e] = val;
+            } else {
+                const float score = __fdiv_rn(-val, a.std);                       // models/utils.py:103
+                total = score;
+                if (a.cgrad != nullptr) total = __fadd_rn(score, __fmul_rn(a.cscale, a.cgrad[e]));  // sampling.py:505
+                if (a.rec_score) a.rec_score[e] = score;
+                if (a.rec_total) a.rec_total[e] = total;
+                noise = a.noise ? a.noise[e] : philox_normal(a.seed, a.stream_offset + e, a.draw);
+                if (a.mode == EXIT_CORRECTOR) {
+                    a.gbuf[e] = total;
+                } else {
+                    // f = sqrt(alpha) x - x ; rev_f = f - G^2 total ; x_mean = x - rev_f ; x = x_mean + G z
+                    const float xv = a.x[e];
+                    const float f = __fsub_rn(__fmul_rn(a.sqrt_alpha, xv), xv);
+                    const float rev_f = __fsub_rn(f, __fmul_rn(a.G2, total));
+                    const float xm = __fsub_rn(xv, rev_f);
+                    const float xn = __fadd_rn(xm, __fmul_rn(a.G, noise));
+                    a.x_mean[e] = xm;
+                    a.x[e] = xn;
+                    if (a.rec_a) a.rec_a[e] = xm;
+                    if (a.rec_b) a.rec_b[e] = xn;
+                }
+            }
+        }
+        tot[i] = total;
+        nz[i] = noise;
+    }
+    if (a.mode != EXIT_CORRECTOR) return;
+    __syncthreads();
+    // per-graph L2 norms (sampling.py:249-250), fixed summation order -> reproducible
+    if (tid < 2 * GF) {
+        const int g = tid % GF;
+        const float *src = (tid < GF) ? tot : nz;
+        float s = 0.f;
+        for (int i = 0; i < N * V; ++i) { const float t = src[g * N * V + i]; s = fmaf(t, t, s); }
+        const float nrm = (blockIdx.x * GF + g < a.batch) ? sqrtf(s) : 0.f;
+        if (tid < GF) gn[g] = nrm; else nn[g] = nrm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float sg = 0.f, sn = 0.f;
+        for (int g = 0; g < GF; ++g) { sg += gn[g]; sn += nn[g]; }
+        a.partials[blockIdx.x] = sg;
+        a.partials[gridDim.x + blockIdx.x] = sn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Langevin corrector update (sampling.py:249-254).  Every block reduces the per-block partial sums
+// in the same fixed order, so all blocks derive the same step size without a grid barrier.
+// ---------------------------------------------------------------------------------------------
+struct CorrArgs {
+    const float *partials; int nparts;   // [2][nparts]
+    int batch; size_t nelem;
+    float snr, alpha;
+    const float *gbuf; float *x;
+    const float *noise; uint64_t seed, stream_offset; uint32_t draw;
+    float *rec_x;                 // [nelem] or null
+    float *rec_step;              // [3] or null
+};
+
+__device__ __forceinline__ float block_sum_256(float v, float *sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] = sh[tid] + sh[tid + s];
+        __syncthreads();
+    }
+    const float out = sh[0];
+    __syncthreads();
+    return out;
+}
+
+__global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x;
+    float sg = 0.f, sn = 0.f;
+    for (int i = tid; i < a.nparts; i += 256) { sg += a.partials[i]; sn += a.partials[a.nparts + i]; }
+    const float grad_norm = block_sum_256(sg, sh) / (float)a.batch;
+    const float noise_norm = block_sum_256(sn, sh) / (float)a.batch;
+    // step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+    const float ratio = __fdiv_rn(__fmul_rn(a.snr, noise_norm), grad_norm);
+    const float step = __fmul_rn(__fmul_rn(__fmul_rn(ratio, ratio), 2.0f), a.alpha);
+    const float nscale = sqrtf(__fmul_rn(step, 2.0f));
+    if (blockIdx.x == 0 && tid == 0 && a.rec_step) {
+        a.rec_step[0] = grad_norm; a.rec_step[1] = noise_norm; a.rec_step[2] = step;
+    }
+    for (size_t e = (size_t)blockIdx.x * 256 + tid; e < a.nelem; e += (size_t)gridDim.x * 256) {
+        const float noise = a.noise ? a.noise[e] : philox_normal(a.seed, a.stream_offset + e, a.draw);
+        const float xm = __fadd_rn(a.x[e], __fmul_rn(step, a.gbuf[e]));
+        const float xn = __fadd_rn(xm, __fmul_rn(nscale, noise));
+        a.x[e] = xn;
+        if (a.rec_x) a.rec_x[e] = xn;
+    }
+}
+
+// x0 = prior sample (sde_lib.py:190-191): copy of the caller's tensor, or Philox draw 0.
+__global__ void prior_kernel(float *x, const float *x0, size_t nelem, uint64_t seed, uint64_t stream_offset) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (size_t)gridDim.x * blockDim.x)
+        x[e] = x0 ? x0[e] : philox_normal(seed, stream_offset + e, 0u);
+}
+
+// out = (x_mean + 1) / 2  (datasets_nas.py:21-28)
+__global__ void inverse_scale_kernel(const float *xm, float *out, size_t nelem) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (size_t)gridDim.x * blockDim.x)
+        out[e] = __fdiv_rn(__fadd_rn(xm[e], 1.0f), 2.0f);
+}
+
+// utils.py:254-255
+__global__ void quantize_kernel(const float *x, float *q, size_t n) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x)
+        q[e] = x[e] >= 0.5f ? 1.0f : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Time embedding MLP: tau = W2 silu(W1 [sin(l w) | cos(l w)] + b1) + b2  (cate.py:155-157, :363-374;
+// digcn_meta.py:116-118, :162-173).  One block per distinct label; d <= 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void time_embed_kernel(const float *__restrict__ labels, int d, const float *__restrict__ freq,
+                                                         const float *__restrict__ W1, const float *__restrict__ b1,
+                                                         const float *__restrict__ W2, const float *__restrict__ b2,
+                                                         float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *e = sm;            // [d]
+    float *hid = sm + d;      // [4d]
+    const int tid = threadIdx.x, half = d / 2;
+    const float lab = labels[blockIdx.x];
+    for (int j = tid; j < d; j += 256) {
+        const float arg = __fmul_rn(lab, freq[j < half ? j : j - half]);
+        e[j] = j < half ? sinf(arg) : cosf(arg);
+    }
+    __syncthreads();
+    for (int i = tid; i < 4 * d; i += 256) {
+        float acc = 0.f;
+        const float *w = W1 + (size_t)i * d;
+        for (int j = 0; j < d; ++j) acc = fmaf(w[j], e[j], acc);
+        hid[i] = silu(acc + b1[i]);
+    }
+    __syncthreads();
+    for (int c = tid; c < d; c += 256) {
+        float acc = 0.f;
+        const float *w = W2 + (size_t)c * 4 * d;
+        for (int i = 0; i < 4 * d; ++i) acc = fmaf(w[i], hid[i], acc);
+        out[(size_t)blockIdx.x * d + c] = acc + b2[c];
+    }
+}

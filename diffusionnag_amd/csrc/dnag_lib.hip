@@ -1,0 +1,518 @@
+// Host side of the dnag C ABI (include/dnag.h): weight packing, workspace carving, kernel launches
+// and the predictor-corrector loop.  Built with hipcc --offload-arch=gfx950 into libdnag.so.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "dnag_common.h"
+#include "dnag_encoder.hip.h"
+#include "dnag_head.hip.h"
+#include "dnag_predictor.hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(DNAG_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int dnag_abi_version(void) { return 1; }
+extern "C" const char *dnag_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// shape checks
+// ---------------------------------------------------------------------------------------------
+static bool is_nb201(const dnag_cate_dims &d) { return d.max_node == 8 && d.n_vocab == 7; }
+static bool is_ofa(const dnag_cate_dims &d) { return d.max_node == 20 && d.n_vocab == 9; }
+
+static int check_cate(const dnag_cate_dims *d) {
+    if (!d) return fail(DNAG_E_ARG, "cate dims is NULL");
+    if (d->d_model != 64 || d->n_head != 8 || d->d_ff != 128)
+        return fail(DNAG_E_ARG, "unsupported CATE width: d_model=%d n_head=%d d_ff=%d (built for 64/8/128)", d->d_model,
+                    d->n_head, d->d_ff);
+    if (d->n_layers < 1 || d->n_layers > 64) return fail(DNAG_E_ARG, "unsupported n_layers=%d", d->n_layers);
+    if (!is_nb201(*d) && !is_ofa(*d))
+        return fail(DNAG_E_ARG, "unsupported graph shape max_node=%d n_vocab=%d (built for 8x7 and 20x9)", d->max_node,
+                    d->n_vocab);
+    return 0;
+}
+
+static int check_pred(const dnag_pred_dims *d) {
+    if (!d) return fail(DNAG_E_ARG, "pred dims is NULL");
+    if (d->max_node != 8 || d->n_vocab != 7)
+        return fail(DNAG_E_ARG, "MetaNeuralPredictor kernel is built for 8x7 graphs, got %dx%d", d->max_node, d->n_vocab);
+    if (d->gcn_hidden != PRED_GH || d->linear_hidden != 128)
+        return fail(DNAG_E_ARG, "unsupported surrogate width gcn_hidden=%d linear_hidden=%d (built for 144/128)",
+                    d->gcn_hidden, d->linear_hidden);
+    if (d->gcn_layers < 1 || d->gcn_layers > DNAG_MAX_GCN) return fail(DNAG_E_ARG, "unsupported gcn_layers=%d", d->gcn_layers);
+    if (d->hs < 1 || d->hs > PRED_MAXHS) return fail(DNAG_E_ARG, "unsupported hs=%d (max %d)", d->hs, PRED_MAXHS);
+    if (d->nz < 1 || d->nz > 1024) return fail(DNAG_E_ARG, "unsupported nz=%d", d->nz);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing (host only)
+// ---------------------------------------------------------------------------------------------
+extern "C" size_t dnag_cate_state_floats(const dnag_cate_dims *c) {
+    if (!c) return 0;
+    const size_t d = c->d_model, V = c->n_vocab, dff = c->d_ff, L = c->n_layers, F = L * d, Hd = 2 * F;
+    size_t n = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d;
+    n += L * (2 * d + 4 * (d * d + d) + 2 * d + dff * d + dff + d * dff + d);
+    n += L * 2 * d;
+    n += Hd * F + Hd + Hd * Hd + Hd + V * Hd + V;
+    return n;
+}
+extern "C" size_t dnag_cate_table_floats(const dnag_cate_dims *c) {
+    return c ? (size_t)c->max_node * c->d_model + c->d_model / 2 : 0;
+}
+extern "C" size_t dnag_cate_packed_floats(const dnag_cate_dims *c) { return c ? cate_layout(*c).total : 0; }
+
+extern "C" int dnag_cate_pack(const dnag_cate_dims *c, const float *s, const float *tables, float *out) {
+    if (int rc = check_cate(c)) return rc;
+    if (!s || !tables || !out) return fail(DNAG_E_ARG, "NULL pointer");
+    const CateLayout y = cate_layout(*c);
+    const size_t d = y.d, V = y.V, dff = y.dff, L = y.L, F = y.F, Hd = y.Hd;
+    memset(out, 0, y.total * sizeof(float));
+    size_t o = 0;
+    auto take = [&](size_t dst, size_t n) { memcpy(out + dst, s + o, n * sizeof(float)); o += n; };
+    take(y.emb_w, d * V); take(y.emb_b, d);
+    take(y.t1_w, 4 * d * d); take(y.t1_b, 4 * d);
+    take(y.t2_w, 4 * d * d); take(y.t2_b, d);
+    // fold gamma/beta of a LayerNorm into the linear that consumes it: W' = W diag(gamma), b' = b + W beta
+    auto fold = [&](const float *W, const float *b, const float *gam, const float *bet, size_t rows, float *Wo, float *bo) {
+        for (size_t r = 0; r < rows; ++r) {
+            double acc = b[r];
+            for (size_t k = 0; k < d; ++k) {
+                Wo[r * d + k] = W[r * d + k] * gam[k];
+                acc += (double)W[r * d + k] * (double)bet[k];
+            }
+            bo[r] = (float)acc;
+        }
+    };
+    for (size_t l = 0; l < L; ++l) {
+        float *LP = out + y.layer0 + l * y.layer_stride;
+        const float *ln1g = s + o, *ln1b = s + o + d; o += 2 * d;
+        for (int j = 0; j < 3; ++j) {   // Q, K, V
+            fold(s + o, s + o + d * d, ln1g, ln1b, d, LP + y.l_wqkv + j * d * d, LP + y.l_bqkv + j * d);
+            o += d * d + d;
+        }
+        memcpy(LP + y.l_wo, s + o, d * d * sizeof(float)); o += d * d;
+        memcpy(LP + y.l_bo, s + o, d * sizeof(float)); o += d;
+        const float *ln2g = s + o, *ln2b = s + o + d; o += 2 * d;
+        fold(s + o, s + o + dff * d, ln2g, ln2b, dff, LP + y.l_w1, LP + y.l_b1); o += dff * d + dff;
+        memcpy(LP + y.l_w2, s + o, d * dff * sizeof(float)); o += d * dff;
+        memcpy(LP + y.l_b2, s + o, d * sizeof(float)); o += d;
+    }
+    for (size_t l = 0; l < L; ++l) {   // encoder_f.norms.l
+        float *LP = out + y.layer0 + l * y.layer_stride;
+        memcpy(LP + y.l_ong, s + o, d * sizeof(float)); o += d;
+        memcpy(LP + y.l_onb, s + o, d * sizeof(float)); o += d;
+    }
+    take(y.f0_w, Hd * F); take(y.f0_b, Hd);
+    take(y.f1_w, Hd * Hd); take(y.f1_b, Hd);
+    take(y.f2_w, V * Hd); take(y.f2_b, V);
+    if (o != dnag_cate_state_floats(c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_cate_state_floats(c));
+    memcpy(out + y.pe, tables, (size_t)y.N * d * sizeof(float));
+    memcpy(out + y.freq, tables + (size_t)y.N * d, (d / 2) * sizeof(float));
+    return 0;
+}
+
+extern "C" size_t dnag_pred_state_floats(const dnag_pred_dims *c) {
+    if (!c) return 0;
+    const size_t g = c->gcn_hidden, V = c->n_vocab, L = c->gcn_layers, lh = c->linear_hidden, hs = c->hs, nz = c->nz;
+    return 2 * V * g + (L - 1) * 2 * g * g + lh * g + 4 * g * g + 4 * g + 4 * g * g + g + hs * (nz + lh) + hs + hs + 1;
+}
+extern "C" size_t dnag_pred_table_floats(const dnag_pred_dims *c) { return c ? (size_t)c->gcn_hidden / 2 : 0; }
+extern "C" size_t dnag_pred_packed_floats(const dnag_pred_dims *c) { return c ? pred_layout(*c).total : 0; }
+
+extern "C" int dnag_pred_pack(const dnag_pred_dims *c, const float *s, const float *tables, float *out) {
+    if (int rc = check_pred(c)) return rc;
+    if (!s || !tables || !out) return fail(DNAG_E_ARG, "NULL pointer");
+    const PredLayout y = pred_layout(*c);
+    const size_t g = y.g, lh = y.lh, hs = y.hs, nz = y.nz;
+    memset(out, 0, y.total * sizeof(float));
+    size_t o = 0;
+    for (int l = 0; l < y.L; ++l) {
+        const size_t in = l == 0 ? (size_t)y.V : g;
+        for (int w = 0; w < 2; ++w) {
+            const float *W = s + o; o += in * g;   // [in][g]
+            float *dst = out + (w ? y.w2[l] : y.w1[l]);
+            float *dstt = out + (w ? y.w2t[l] : y.w1t[l]);
+            memcpy(dst, W, in * g * sizeof(float));
+            for (size_t i = 0; i < in; ++i)
+                for (size_t k = 0; k < g; ++k) dstt[k * in + i] = W[i * g + k];
+        }
+    }
+    {
+        const float *W = s + o; o += lh * g;   // fc1 [lh][g]
+        memcpy(out + y.fc1, W, lh * g * sizeof(float));
+        for (size_t i = 0; i < lh; ++i)
+            for (size_t k = 0; k < g; ++k) out[y.fc1t + k * lh + i] = W[i * g + k];
+    }
+    memcpy(out + y.t1_w, s + o, 4 * g * g * sizeof(float)); o += 4 * g * g;
+    memcpy(out + y.t1_b, s + o, 4 * g * sizeof(float)); o += 4 * g;
+    memcpy(out + y.t2_w, s + o, 4 * g * g * sizeof(float)); o += 4 * g * g;
+    memcpy(out + y.t2_b, s + o, g * sizeof(float)); o += g;
+    {
+        const float *W = s + o; o += hs * (nz + lh);   // pred_fc.0 [hs][nz+lh]
+        memcpy(out + y.p0_w, W, hs * (nz + lh) * sizeof(float));
+        for (size_t j = 0; j < hs; ++j)
+            for (size_t a = 0; a < lh; ++a) out[y.p0_at + a * hs + j] = W[j * (nz + lh) + nz + a];
+    }
+    memcpy(out + y.p0_b, s + o, hs * sizeof(float)); o += hs;
+    memcpy(out + y.p2_w, s + o, hs * sizeof(float)); o += hs;
+    out[y.p2_b] = s[o]; o += 1;
+    if (o != dnag_pred_state_floats(c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_pred_state_floats(c));
+    memcpy(out + y.freq, tables, (g / 2) * sizeof(float));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------
+struct WsLayout {
+    size_t rows, rows_pad;
+    size_t labels, temb_s, temb_p, concat, h1, h2, cgrad, gbuf, x, x_mean, partials, total;   // float offsets
+    int nblk_exit;
+};
+
+static size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int exit_gf(const dnag_cate_dims &c) { return is_nb201(c) ? 8 : 3; }
+
+static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int batch, int n_steps) {
+    WsLayout w;
+    const size_t N = c.max_node, V = c.n_vocab, F = (size_t)c.n_layers * c.d_model, Hd = 2 * F;
+    const size_t nt = (size_t)(n_steps > batch ? n_steps : batch);
+    w.rows = (size_t)batch * N;
+    w.rows_pad = up(w.rows, GEMM_BM);
+    w.nblk_exit = (batch + exit_gf(c) - 1) / exit_gf(c);
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += up(n, 64); return at; };
+    w.labels = take(nt);
+    w.temb_s = take(nt * c.d_model);
+    w.temb_p = take(p ? nt * p->gcn_hidden : 0);
+    w.concat = take(w.rows_pad * F);
+    w.h1 = take(w.rows_pad * Hd);
+    w.h2 = take(w.rows_pad * Hd);
+    w.cgrad = take((size_t)batch * N * V);
+    w.gbuf = take((size_t)batch * N * V);
+    w.x = take((size_t)batch * N * V);
+    w.x_mean = take((size_t)batch * N * V);
+    w.partials = take(2 * (size_t)w.nblk_exit);
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t dnag_workspace_bytes(const dnag_cate_dims *cd, const dnag_pred_dims *pd, int batch, int n_steps) {
+    if (!cd || batch < 1) return 0;
+    return ws_layout(*cd, pd, batch, n_steps < 1 ? 1 : n_steps).total * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel timing (bench.py roofline): event pairs around every `every`-th head GEMM (K = 2F) launch
+// ---------------------------------------------------------------------------------------------
+struct Timing {
+    bool on = false;
+    int every = 1, max_samples = 0, seen = 0;
+    std::vector<hipEvent_t> ev0, ev1;
+    int used = 0;
+    double flops = 0.0;
+};
+static Timing g_tm;
+static std::mutex g_tm_mu;
+
+extern "C" int dnag_timing_begin(int every, int max_samples) {
+    std::lock_guard<std::mutex> lk(g_tm_mu);
+    if (g_tm.on) return fail(DNAG_E_ARG, "timing already enabled");
+    if (every < 1 || max_samples < 1 || max_samples > 65536) return fail(DNAG_E_ARG, "bad timing arguments");
+    g_tm.ev0.resize(max_samples); g_tm.ev1.resize(max_samples);
+    for (int i = 0; i < max_samples; ++i) { HIP_TRY(hipEventCreate(&g_tm.ev0[i])); HIP_TRY(hipEventCreate(&g_tm.ev1[i])); }
+    g_tm.every = every; g_tm.max_samples = max_samples; g_tm.seen = 0; g_tm.used = 0; g_tm.flops = 0.0; g_tm.on = true;
+    return 0;
+}
+extern "C" int dnag_timing_read(int *n_samples, double *mean_ms, double *flops_per_launch) {
+    std::lock_guard<std::mutex> lk(g_tm_mu);
+    if (!g_tm.on) return fail(DNAG_E_ARG, "timing not enabled");
+    double tot = 0.0;
+    for (int i = 0; i < g_tm.used; ++i) {
+        HIP_TRY(hipEventSynchronize(g_tm.ev1[i]));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, g_tm.ev0[i], g_tm.ev1[i]));
+        tot += ms;
+    }
+    if (n_samples) *n_samples = g_tm.used;
+    if (mean_ms) *mean_ms = g_tm.used ? tot / g_tm.used : 0.0;
+    if (flops_per_launch) *flops_per_launch = g_tm.flops;
+    return 0;
+}
+extern "C" int dnag_timing_end(void) {
+    std::lock_guard<std::mutex> lk(g_tm_mu);
+    if (!g_tm.on) return 0;
+    for (int i = 0; i < g_tm.max_samples; ++i) { hipEventDestroy(g_tm.ev0[i]); hipEventDestroy(g_tm.ev1[i]); }
+    g_tm.ev0.clear(); g_tm.ev1.clear(); g_tm.on = false;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+static int launch_gemm(const float *A, const float *W, const float *bias, float *C, size_t M, int Nout, int K, bool timed,
+                       size_t real_rows, hipStream_t st) {
+    if (M % GEMM_BM || Nout % GEMM_BN || K % GEMM_BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
+    const int grid = (int)(M / GEMM_BM) * (Nout / GEMM_BN);
+    int slot = -1;
+    if (timed) {
+        std::lock_guard<std::mutex> lk(g_tm_mu);
+        if (g_tm.on) {
+            if (g_tm.seen % g_tm.every == 0 && g_tm.used < g_tm.max_samples) slot = g_tm.used++;
+            g_tm.seen++;
+            g_tm.flops = 2.0 * (double)real_rows * (double)Nout * (double)K;
+        }
+    }
+    if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev0[slot], st));
+    // two instantiations so that profiles list final.linears.0 (K = F) and final.linears.1 (K = 2F) apart
+    if (timed)
+        hipLaunchKernelGGL((gemm_bias_act_kernel<true, 1>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
+    else
+        hipLaunchKernelGGL((gemm_bias_act_kernel<true, 0>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
+    LAUNCH_CHECK();
+    if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
+    return 0;
+}
+
+static int launch_time_embed(const float *labels, int n, int d, const float *P, size_t freq, size_t w1, size_t b1, size_t w2,
+                             size_t b2, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(time_embed_kernel, dim3(n), dim3(256), (size_t)5 * d * sizeof(float), st, labels, d, P + freq, P + w1,
+                       P + b1, P + w2, P + b2, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <int N, int V, int G>
+static int launch_encoder_t(const CateLayout &lay, const float *P, const float *x, const float *temb, int tstride,
+                            const float *mask, int mstride, float *concat, float *attn0, int batch, hipStream_t st) {
+    typedef EncGeom<N, G, 128> Ge;
+    const size_t lds = Ge::lds_floats * sizeof(float);
+    auto kern = encoder_kernel<N, V, G, 8, 128, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int grid = (batch + G - 1) / G;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_encoder(const dnag_cate_dims &c, const CateLayout &lay, const float *P, const float *x, const float *temb,
+                          int tstride, const float *mask, int mstride, float *concat, float *attn0, int batch, hipStream_t st) {
+    if (is_nb201(c)) return launch_encoder_t<8, 7, 8>(lay, P, x, temb, tstride, mask, mstride, concat, attn0, batch, st);
+    return launch_encoder_t<20, 9, 3>(lay, P, x, temb, tstride, mask, mstride, concat, attn0, batch, st);
+}
+
+static int launch_exit(const dnag_cate_dims &c, const CateLayout &lay, const float *P, const float *h2, const ExitArgs &a,
+                       hipStream_t st) {
+    const int gf = exit_gf(c);
+    const int grid = (a.batch + gf - 1) / gf;
+    if (is_nb201(c))
+        hipLaunchKernelGGL((head_out_kernel<8, 7, 8>), dim3(grid), dim3(256), 0, st, h2, P + lay.f2_w, P + lay.f2_b, lay.Hd, a);
+    else
+        hipLaunchKernelGGL((head_out_kernel<20, 9, 3>), dim3(grid), dim3(256), 0, st, h2, P + lay.f2_w, P + lay.f2_b, lay.Hd, a);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_predictor(const PredLayout &lay, const float *P, const float *x, const float *temb, int tstride,
+                            const float *mask, int mstride, const float *d_mu, float *y, float *grad, int batch, hipStream_t st) {
+    typedef PredGeom<8, 7, 4> Ge;
+    const size_t lds = Ge::lds_bytes(lay.hs, lay.L);
+    auto kern = predictor_kernel<8, 7, 4>;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int grid = (batch + 3) / 4;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, d_mu, y, grad, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// score-network body: x -> H2 (everything but the exit kernel)
+static int run_score_body(const dnag_cate_dims &c, const CateLayout &lay, const float *P, const float *x, const float *temb,
+                          int tstride, const float *mask, int mstride, float *ws, const WsLayout &w, float *attn0, int batch,
+                          hipStream_t st) {
+    if (int rc = launch_encoder(c, lay, P, x, temb, tstride, mask, mstride, ws + w.concat, attn0, batch, st)) return rc;
+    if (int rc = launch_gemm(ws + w.concat, P + lay.f0_w, P + lay.f0_b, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st)) return rc;
+    if (int rc = launch_gemm(ws + w.h1, P + lay.f1_w, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st)) return rc;
+    return 0;
+}
+
+extern "C" int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, const float *x, const float *time_cond,
+                                 int time_stride, const float *mask, int mask_stride, float *out, float *concat_out,
+                                 float *attn0_out, int batch, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = check_cate(d)) return rc;
+    if (!packed || !x || !time_cond || !mask || !out || !workspace) return fail(DNAG_E_ARG, "NULL pointer");
+    if (batch < 1) return fail(DNAG_E_ARG, "batch=%d", batch);
+    const CateLayout lay = cate_layout(*d);
+    const WsLayout w = ws_layout(*d, nullptr, batch, 1);
+    if (workspace_bytes < w.total * sizeof(float))
+        return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, w.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const int nt = time_stride ? batch : 1;
+    if (int rc = launch_time_embed(time_cond, nt, lay.d, packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, ws + w.temb_s, st)) return rc;
+    if (int rc = run_score_body(*d, lay, packed, x, ws + w.temb_s, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, ws, w, attn0_out, batch, st)) return rc;
+    ExitArgs a;
+    memset(&a, 0, sizeof(a));
+    a.mode = EXIT_FORWARD; a.batch = batch; a.out = out;
+    if (int rc = launch_exit(*d, lay, packed, ws + w.h2, a, st)) return rc;
+    if (concat_out)
+        HIP_TRY(hipMemcpyAsync(concat_out, ws + w.concat, w.rows * lay.F * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *packed, const float *x, const float *time_cond,
+                                      int time_stride, const float *mask, int mask_stride, const float *d_mu, float *y,
+                                      float *grad, int batch, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = check_pred(d)) return rc;
+    if (!packed || !x || !time_cond || !mask || !d_mu || !workspace) return fail(DNAG_E_ARG, "NULL pointer");
+    if (batch < 1) return fail(DNAG_E_ARG, "batch=%d", batch);
+    const PredLayout lay = pred_layout(*d);
+    const size_t nt = time_stride ? batch : 1;
+    if (workspace_bytes < nt * lay.g * sizeof(float))
+        return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, nt * lay.g * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float *temb = (float *)workspace;
+    if (int rc = launch_time_embed(time_cond, (int)nt, lay.g, packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, temb, st)) return rc;
+    return launch_predictor(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, d_mu, y, grad, batch, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// predictor-corrector loop
+// ---------------------------------------------------------------------------------------------
+extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
+    if (!p) return fail(DNAG_E_ARG, "args is NULL");
+    if (int rc = check_cate(p->cate_dims)) return rc;
+    const bool guided = p->pred_dims != nullptr;
+    if (guided) {
+        if (int rc = check_pred(p->pred_dims)) return rc;
+        if (!p->pred_packed || !p->d_mu) return fail(DNAG_E_ARG, "guided sampling needs pred_packed and d_mu");
+        if (p->pred_dims->max_node != p->cate_dims->max_node || p->pred_dims->n_vocab != p->cate_dims->n_vocab)
+            return fail(DNAG_E_ARG, "score net and surrogate disagree on the graph shape");
+        if (!(p->label_sign == 1.0f || p->label_sign == -1.0f)) return fail(DNAG_E_ARG, "label_sign must be +1 or -1");
+    }
+    if (!p->cate_packed || !p->mask || !p->sched || !p->x_out || !p->workspace) return fail(DNAG_E_ARG, "NULL pointer");
+    if (p->batch < 1 || p->n_steps < 1) return fail(DNAG_E_ARG, "batch=%d n_steps=%d", p->batch, p->n_steps);
+    if ((p->noise_corr == nullptr) != (p->noise_pred == nullptr) && p->corrector)
+        return fail(DNAG_E_ARG, "noise_corr and noise_pred must both be given (tape mode) or both NULL (Philox)");
+    const dnag_cate_dims &cd = *p->cate_dims;
+    const CateLayout lay = cate_layout(cd);
+    const WsLayout w = ws_layout(cd, p->pred_dims, p->batch, p->n_steps);
+    if (p->workspace_bytes < w.total * sizeof(float))
+        return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", p->workspace_bytes, w.total * sizeof(float));
+    hipStream_t st = (hipStream_t)p->stream;
+    float *ws = (float *)p->workspace;
+    const int B = p->batch, S = p->n_steps;
+    const size_t nelem = (size_t)B * cd.max_node * cd.n_vocab;
+    PredLayout play;
+    if (guided) play = pred_layout(*p->pred_dims);
+
+    // labels -> device, time embeddings of every step in one launch per network
+    std::vector<float> labels(S);
+    for (int i = 0; i < S; ++i) {
+        const float *row = p->sched + (size_t)i * DNAG_SCHED_COLS;
+        if (!(row[DNAG_SCHED_STD] > 0.f)) return fail(DNAG_E_ARG, "sched[%d].std = %g is not positive", i, row[DNAG_SCHED_STD]);
+        labels[i] = row[DNAG_SCHED_LABEL];
+    }
+    HIP_TRY(hipMemcpyAsync(ws + w.labels, labels.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // `labels` is pageable host memory that dies with this call
+    if (int rc = launch_time_embed(ws + w.labels, S, lay.d, p->cate_packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, ws + w.temb_s, st)) return rc;
+    if (guided)
+        if (int rc = launch_time_embed(ws + w.labels, S, play.g, p->pred_packed, play.freq, play.t1_w, play.t1_b, play.t2_w, play.t2_b, ws + w.temb_p, st)) return rc;
+
+    float *x = ws + w.x, *x_mean = ws + w.x_mean, *cgrad = ws + w.cgrad, *gbuf = ws + w.gbuf, *partials = ws + w.partials;
+    hipLaunchKernelGGL(prior_kernel, dim3(1024), dim3(256), 0, st, x, p->x0, nelem, p->seed, p->stream_offset);
+    LAUNCH_CHECK();
+
+    auto rec_at = [&](float *base, int i) -> float * { return base ? base + (size_t)i * nelem : nullptr; };
+
+    for (int i = 0; i < S; ++i) {
+        const float *row = p->sched + (size_t)i * DNAG_SCHED_COLS;
+        for (int phase = p->corrector ? 0 : 1; phase < 2; ++phase) {
+            const bool corr = phase == 0;
+            if (guided) {
+                if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, p->d_mu, nullptr, cgrad, B, st)) return rc;
+                float *rc_ = rec_at(corr ? p->rec_cgrad_c : p->rec_cgrad_p, i);
+                if (rc_) HIP_TRY(hipMemcpyAsync(rc_, cgrad, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+            if (int rc = run_score_body(cd, lay, p->cate_packed, x, ws + w.temb_s + (size_t)i * lay.d, 0, p->mask, 0, ws, w, nullptr, B, st)) return rc;
+            ExitArgs a;
+            memset(&a, 0, sizeof(a));
+            a.mode = corr ? EXIT_CORRECTOR : EXIT_PREDICTOR;
+            a.batch = B;
+            a.std = row[DNAG_SCHED_STD];
+            a.cgrad = guided ? cgrad : nullptr;
+            a.cscale = p->classifier_scale * p->label_sign;
+            a.gbuf = gbuf; a.partials = partials;
+            a.x = x; a.x_mean = x_mean;
+            a.sqrt_alpha = row[DNAG_SCHED_SQRTA]; a.G = row[DNAG_SCHED_G]; a.G2 = row[DNAG_SCHED_G2];
+            const float *tape = corr ? p->noise_corr : p->noise_pred;
+            a.noise = tape ? tape + (size_t)i * nelem : nullptr;
+            a.seed = p->seed; a.stream_offset = p->stream_offset; a.draw = (uint32_t)(1 + 2 * i + (corr ? 0 : 1));
+            a.rec_score = rec_at(corr ? p->rec_score_c : p->rec_score_p, i);
+            a.rec_total = rec_at(corr ? p->rec_total_c : p->rec_total_p, i);
+            a.rec_a = corr ? nullptr : rec_at(p->rec_x_mean, i);
+            a.rec_b = corr ? nullptr : rec_at(p->rec_x_pred, i);
+            if (int rc = launch_exit(cd, lay, p->cate_packed, ws + w.h2, a, st)) return rc;
+            if (corr) {
+                CorrArgs c;
+                memset(&c, 0, sizeof(c));
+                c.partials = partials; c.nparts = w.nblk_exit; c.batch = B; c.nelem = nelem;
+                c.snr = p->snr; c.alpha = row[DNAG_SCHED_ALPHA];
+                c.gbuf = gbuf; c.x = x;
+                c.noise = a.noise; c.seed = a.seed; c.stream_offset = a.stream_offset; c.draw = a.draw;
+                c.rec_x = rec_at(p->rec_x_corr, i);
+                c.rec_step = p->rec_step_size ? p->rec_step_size + (size_t)i * 3 : nullptr;
+                const int grid = (int)((nelem + 255) / 256 < 2048 ? (nelem + 255) / 256 : 2048);
+                hipLaunchKernelGGL(corrector_update_kernel, dim3(grid), dim3(256), 0, st, c);
+                LAUNCH_CHECK();
+            }
+        }
+    }
+    hipLaunchKernelGGL(inverse_scale_kernel, dim3(1024), dim3(256), 0, st, x_mean, p->x_out, nelem);
+    LAUNCH_CHECK();
+    if (p->x_last) HIP_TRY(hipMemcpyAsync(p->x_last, x, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (p->x_mean_last) HIP_TRY(hipMemcpyAsync(p->x_mean_last, x_mean, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int dnag_quantize(const float *x, float *q, size_t n, void *stream) {
+    if (!x || !q) return fail(DNAG_E_ARG, "NULL pointer");
+    if (n == 0) return 0;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(quantize_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, q, n);
+    LAUNCH_CHECK();
+    return 0;
+}

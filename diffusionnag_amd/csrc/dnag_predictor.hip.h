@@ -1,0 +1,335 @@
+// MetaNeuralPredictor surrogate: forward and analytic input gradient, one workgroup per G graphs,
+// all activations in LDS.  Included by dnag_lib.hip.
+//
+// Restates (reference NAS-Bench-201/): models/digcn_meta.py:109-129 (arch_encode), :39-48
+// (DirectedGraphConvolution), :12-22 (normalize_adj, graph_pooling), :141-159 (predict/forward) and
+// the autograd call of models/utils.py:130-145 (regress=True) as a hand-derived backward pass.
+//
+//   Ahat = rn(M + I);  A1 = rn(Ahat);  A2 = rn(Ahat^T)                (rn: divide rows by their sums)
+//   H_{l+1} = 1/2 [relu(A1 (H_l W1_l)) + relu(A2 (H_l W2_l))]         evaluated as (A1 H_l) W1_l
+//   p = sum_n H_L[n] / N + tau ;  a = Wfc1 p ;  y = w2 . tanh(W0 [D_mu | a] + b0) + b2
+// Backward (dy/dx only): dpre = w2 (1 - tanh^2); da = W0[:, nz:]^T dpre; dp = Wfc1^T da;
+//   dH_L[n] = dp / N;  per layer  dH_l = (A1^T (1/2 dH_{l+1} . [Z1>0])) W1^T + (A2^T (...[Z2>0])) W2^T.
+#pragma once
+#include "dnag_common.h"
+#include "dnag_encoder.hip.h"
+
+#define PRED_GH 144        // gcn_hidden (configs/tr_meta_surrogate.py:97)
+#define PRED_HS 148        // LDS row stride of [R][144] buffers (148 % 64 == 20: conflict-free b128 reads)
+#define PRED_NT 5          // ceil(144 / 32) column tiles
+#define PRED_NW 5          // waves per workgroup: one column tile each
+#define PRED_MAXHS 512
+
+template <int N, int V, int G>
+struct PredGeom {
+    static constexpr int R = G * N;
+    static_assert(R == 32, "one 32-row MFMA tile per workgroup");
+    static constexpr int XF = (R * V + 11) / 4 * 4;                   // staged x, padded
+    // dynamic LDS bytes for `hs` head units and `L` DiGCN layers
+    static size_t lds_bytes(int hs, int L) {
+        const size_t hs4 = align4((size_t)hs);
+        const size_t fl = 3 * (size_t)R * PRED_HS      // H, U1, U2
+                          + 2 * (size_t)G * N * N      // A1, A2
+                          + (size_t)G * PRED_GH        // pbar / dp
+                          + (size_t)G * 128            // a / da
+                          + (size_t)G * hs4            // tanh / dpre
+                          + hs4                        // c0
+                          + XF                         // x
+                          + (size_t)L * 2 * R * PRED_NT;   // relu bit masks (uint32)
+        return fl * sizeof(float);
+    }
+};
+
+// x [batch][N][V]; temb [tstride ? batch : 1][144]; mask [mstride ? batch : 1][N][N]; d_mu [nz];
+// y [batch] or null; grad [batch][N][V] or null.
+template <int N, int V, int G>
+__global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float *__restrict__ P, const PredLayout lay,
+                                                                    const float *__restrict__ x, const float *__restrict__ temb,
+                                                                    int tstride, const float *__restrict__ mask, int mstride,
+                                                                    const float *__restrict__ d_mu, float *__restrict__ y,
+                                                                    float *__restrict__ grad, int batch) {
+    typedef PredGeom<N, V, G> Ge;
+    constexpr int R = Ge::R, HS = PRED_HS, GH = PRED_GH, NT = PRED_NW * 64, LH = 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Hb = smem;                       // [R][HS]
+    float *U1 = Hb + R * HS;                // [R][HS]
+    float *U2 = U1 + R * HS;                // [R][HS]
+    float *A1 = U2 + R * HS;                // [G][N][N]
+    float *A2 = A1 + G * N * N;             // [G][N][N]
+    float *pbar = A2 + G * N * N;           // [G][GH]
+    float *avec = pbar + G * GH;            // [G][LH]
+    const int L = lay.L, hs = lay.hs, nz = lay.nz;
+    const int TS = (hs + 3) & ~3;           // row stride of tv
+    float *tv = avec + G * LH;              // [G][TS]
+    float *c0 = tv + G * TS;                // [TS]
+    float *xin = c0 + TS;                   // [R][V]
+    uint32_t *bits = reinterpret_cast<uint32_t *>(xin + Ge::XF);   // [L][2][R][NT] (cols of tile nt, row r)
+    float *Ah = U1;                         // scratch for Ahat during set-up
+
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * G;
+
+    // ---- inputs ---------------------------------------------------------------------------------
+    for (int i = tid; i < R * V; i += NT) {
+        const int g = i / (N * V);
+        xin[i] = (g0 + g < batch) ? x[(size_t)g0 * N * V + i] : 0.f;
+    }
+    // Ahat = rn(M + I)   (digcn_meta.py:120)
+    for (int i = tid; i < G * N; i += NT) {
+        const int g = i / N, r = i - g * N;
+        const int gg = (g0 + g < batch) ? g0 + g : 0;
+        const float *m = mask + (size_t)(mstride ? gg : 0) * N * N + r * N;
+        float row[N], s = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { row[j] = m[j] + (j == r ? 1.f : 0.f); s += row[j]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) Ah[(g * N + r) * N + j] = row[j] / s;
+    }
+    __syncthreads();
+    // A1 = rn(Ahat), A2 = rn(Ahat^T)   (digcn_meta.py:42, :44)
+    for (int i = tid; i < G * N; i += NT) {
+        const int g = i / N, r = i - g * N;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) { s1 += Ah[(g * N + r) * N + j]; s2 += Ah[(g * N + j) * N + r]; }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            A1[(g * N + r) * N + j] = Ah[(g * N + r) * N + j] / s1;
+            A2[(g * N + r) * N + j] = Ah[(g * N + j) * N + r] / s2;
+        }
+    }
+    // c0 = b0 + W0[:, :nz] D_mu   (the dataset half of pred_fc.0, constant per call)
+    for (int j = tid; j < hs; j += NT) {
+        const float *w = P + lay.p0_w + (size_t)j * (nz + LH);
+        float acc = 0.f;
+        for (int z = 0; z < nz; ++z) acc = fmaf(w[z], d_mu[z], acc);
+        c0[j] = acc + P[lay.p0_b + j];
+    }
+    __syncthreads();   // Ah (aliasing U1) is dead from here
+
+    // ---- layer 0: K = V, plain FMAs -----------------------------------------------------------
+    {
+        // U[r][v] = sum_r' A[r][r'] x[r'][v] -> kept in registers per (r, c) item below
+        const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]
+        for (int i = tid; i < R * GH; i += NT) {
+            const int r = i / GH, c = i - r * GH;
+            const int g = r / N, n = r - g * N;
+            float z1 = 0.f, z2 = 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float xv = xin[(g * N + j) * V + v];
+                    u1 = fmaf(A1[(g * N + n) * N + j], xv, u1);
+                    u2 = fmaf(A2[(g * N + n) * N + j], xv, u2);
+                }
+                z1 = fmaf(u1, W1[v * GH + c], z1);
+                z2 = fmaf(u2, W2[v * GH + c], z2);
+            }
+            Hb[r * HS + c] = (fmaxf(z1, 0.f) + fmaxf(z2, 0.f)) / 2.f;
+            // relu masks of layer 0 as bytes packed later: store sign bits in U1/U2 scratch
+            U1[r * HS + c] = z1 > 0.f ? 1.f : 0.f;
+            U2[r * HS + c] = z2 > 0.f ? 1.f : 0.f;
+        }
+        __syncthreads();
+        // pack layer-0 masks into bit words: word (which, r, nt) covers cols nt*32 .. nt*32+31
+        for (int i = tid; i < 2 * R * PRED_NT; i += NT) {
+            const int nt = i % PRED_NT, r = (i / PRED_NT) % R, which = i / (PRED_NT * R);
+            const float *src = which ? U2 : U1;
+            uint32_t w = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int c = nt * 32 + b;
+                if (c < GH && src[r * HS + c] != 0.f) w |= (1u << b);
+            }
+            bits[(size_t)(0 * 2 + which) * R * PRED_NT + r * PRED_NT + nt] = w;
+        }
+        __syncthreads();
+    }
+
+    auto id_xf = [](v4f a, int) { return a; };
+    auto mix_fwd = [&]() {   // U1 = A1 H, U2 = A2 H  (per graph)
+        for (int i = tid; i < R * GH; i += NT) {
+            const int r = i / GH, c = i - r * GH;
+            const int g = r / N, n = r - g * N;
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float hv = Hb[(g * N + j) * HS + c];
+                u1 = fmaf(A1[(g * N + n) * N + j], hv, u1);
+                u2 = fmaf(A2[(g * N + n) * N + j], hv, u2);
+            }
+            U1[r * HS + c] = u1;
+            U2[r * HS + c] = u2;
+        }
+    };
+
+    // ---- layers 1 .. L-1 forward -----------------------------------------------------------------
+    for (int l = 1; l < L; ++l) {
+        mix_fwd();
+        __syncthreads();
+        const float *W1t = P + lay.w1t[l], *W2t = P + lay.w2t[l];   // [GH out][GH in]
+        uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
+        f32x16 acc1;
+        // each wave owns one column tile; Z1 and Z2 computed back to back with the same registers
+        run_jobs<GH, 1, PRED_NW>(
+            PRED_NT, U1, HS,
+            [&](int nt, int r, int h, float (&b)[GH / 2]) {
+                const int col = nt * 32 + r;
+                if (col < GH) load_row<GH / 2>(W1t + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
+            },
+            id_xf, [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
+        run_jobs<GH, 1, PRED_NW>(
+            PRED_NT, U2, HS,
+            [&](int nt, int r, int h, float (&b)[GH / 2]) {
+                const int col = nt * 32 + r;
+                if (col < GH) load_row<GH / 2>(W2t + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
+            },
+            id_xf,
+            [&](int, int nt, int r, int h, const f32x16 &acc2) {
+                const int col = nt * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = acc_row(i, h);
+                    const unsigned long long m1 = __ballot(acc1[i] > 0.f), m2 = __ballot(acc2[i] > 0.f);
+                    if (r == 0) {   // lanes 0 and 32: one word per (row, tile) and mask
+                        bl[(0 * R + row) * PRED_NT + nt] = (uint32_t)(h ? (m1 >> 32) : m1);
+                        bl[(1 * R + row) * PRED_NT + nt] = (uint32_t)(h ? (m2 >> 32) : m2);
+                    }
+                    if (col < GH) Hb[row * HS + col] = (fmaxf(acc1[i], 0.f) + fmaxf(acc2[i], 0.f)) / 2.f;
+                }
+            });
+        __syncthreads();
+    }
+
+    // ---- head forward -----------------------------------------------------------------------------
+    for (int i = tid; i < G * GH; i += NT) {
+        const int g = i / GH, c = i - g * GH;
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < N; ++n) s += Hb[(g * N + n) * HS + c];
+        const int gg = (g0 + g < batch) ? g0 + g : 0;
+        pbar[i] = s / (float)N + temb[(size_t)(tstride ? gg : 0) * GH + c];   // digcn_meta.py:19-22, :125
+    }
+    __syncthreads();
+    for (int i = tid; i < G * LH; i += NT) {   // a = Wfc1 p  (fc1t [GH][LH])
+        const int g = i / LH, o = i - g * LH;
+        const float *w = P + lay.fc1t + o;
+        float acc = 0.f;
+        for (int c = 0; c < GH; ++c) acc = fmaf(w[(size_t)c * LH], pbar[g * GH + c], acc);
+        avec[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < G * hs; i += NT) {   // tanh(W0a a + c0)  (p0_at [LH][hs])
+        const int g = i / hs, j = i - g * hs;
+        const float *w = P + lay.p0_at + j;
+        float acc = 0.f;
+        for (int o = 0; o < LH; ++o) acc = fmaf(w[(size_t)o * hs], avec[g * LH + o], acc);
+        tv[g * TS + j] = tanhf(acc + c0[j]);
+    }
+    __syncthreads();
+    if (y != nullptr && tid < G && g0 + tid < batch) {
+        float acc = 0.f;
+        for (int j = 0; j < hs; ++j) acc = fmaf(P[lay.p2_w + j], tv[tid * TS + j], acc);
+        y[g0 + tid] = acc + P[lay.p2_b];
+    }
+    if (grad == nullptr) return;
+    __syncthreads();
+
+    // ---- head backward ----------------------------------------------------------------------------
+    for (int i = tid; i < G * hs; i += NT) {   // dpre = w2 (1 - tanh^2)
+        const int g = i / hs, j = i - g * hs;
+        const float t = tv[g * TS + j];
+        tv[g * TS + j] = P[lay.p2_w + j] * (1.f - t * t);
+    }
+    __syncthreads();
+    for (int i = tid; i < G * LH; i += NT) {   // da[o] = sum_j W0[j][nz + o] dpre[j]
+        const int g = i / LH, o = i - g * LH;
+        const float *w = P + lay.p0_w + nz + o;
+        float acc = 0.f;
+        for (int j = 0; j < hs; ++j) acc = fmaf(w[(size_t)j * (nz + LH)], tv[g * TS + j], acc);
+        avec[i] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < G * GH; i += NT) {   // dp[c] = sum_o Wfc1[o][c] da[o];  dH_L[n][c] = dp[c] / N
+        const int g = i / GH, c = i - g * GH;
+        const float *w = P + lay.fc1 + c;
+        float acc = 0.f;
+        for (int o = 0; o < LH; ++o) acc = fmaf(w[(size_t)o * GH], avec[g * LH + o], acc);
+        pbar[i] = acc / (float)N;
+    }
+    __syncthreads();
+    for (int i = tid; i < R * GH; i += NT) {
+        const int r = i / GH, c = i - r * GH;
+        Hb[r * HS + c] = pbar[(r / N) * GH + c];
+    }
+    __syncthreads();
+
+    // P1 = A1^T (1/2 dH . m1), P2 = A2^T (1/2 dH . m2) into U1, U2
+    auto mix_bwd = [&](int l) {
+        const uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
+        for (int i = tid; i < R * GH; i += NT) {
+            const int r = i / GH, c = i - r * GH;
+            const int g = r / N, n = r - g * N;
+            const int nt = c >> 5, bit = c & 31;
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int rj = g * N + j;
+                const float dh = Hb[rj * HS + c] * 0.5f;
+                const float d1 = ((bl[(0 * R + rj) * PRED_NT + nt] >> bit) & 1u) ? dh : 0.f;
+                const float d2 = ((bl[(1 * R + rj) * PRED_NT + nt] >> bit) & 1u) ? dh : 0.f;
+                p1 = fmaf(A1[rj * N + n], d1, p1);
+                p2 = fmaf(A2[rj * N + n], d2, p2);
+            }
+            U1[r * HS + c] = p1;
+            U2[r * HS + c] = p2;
+        }
+    };
+
+    // ---- layers L-1 .. 1 backward: dH_l = P1 W1^T + P2 W2^T  (B rows = W[in][:] K-contiguous) ------
+    for (int l = L - 1; l >= 1; --l) {
+        mix_bwd(l);
+        __syncthreads();
+        const float *W1 = P + lay.w1[l], *W2 = P + lay.w2[l];   // [GH in][GH out]
+        f32x16 acc1;
+        run_jobs<GH, 1, PRED_NW>(
+            PRED_NT, U1, HS,
+            [&](int nt, int r, int h, float (&b)[GH / 2]) {
+                const int col = nt * 32 + r;
+                if (col < GH) load_row<GH / 2>(W1 + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
+            },
+            id_xf, [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
+        run_jobs<GH, 1, PRED_NW>(
+            PRED_NT, U2, HS,
+            [&](int nt, int r, int h, float (&b)[GH / 2]) {
+                const int col = nt * 32 + r;
+                if (col < GH) load_row<GH / 2>(W2 + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
+            },
+            id_xf,
+            [&](int, int nt, int r, int h, const f32x16 &acc2) {
+                const int col = nt * 32 + r;
+                if (col < GH) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) Hb[acc_row(i, h) * HS + col] = acc1[i] + acc2[i];
+                }
+            });
+        __syncthreads();
+    }
+    // ---- layer 0 backward: dx[r][v] = sum_c P1[r][c] W1[v][c] + P2[r][c] W2[v][c] -------------------
+    mix_bwd(0);
+    __syncthreads();
+    {
+        const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]
+        for (int i = tid; i < R * V; i += NT) {
+            const int r = i / V, v = i - r * V;
+            const int g = r / N;
+            float acc = 0.f;
+            for (int c = 0; c < GH; ++c) {
+                acc = fmaf(U1[r * HS + c], W1[v * GH + c], acc);
+                acc = fmaf(U2[r * HS + c], W2[v * GH + c], acc);
+            }
+            if (g0 + g < batch) grad[(size_t)g0 * N * V + i] = acc;
+        }
+    }
+}

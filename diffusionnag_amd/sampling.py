@@ -1,0 +1,293 @@
+"""Host mirror of the reference's ``sampling.py`` factory surface (reference ``sampling.py:14-133``,
+``:380-447``, ``:450-579``): the same registries, ``get_sampling_fn`` signature and sampler call
+signatures / return values.  The loop itself -- Langevin corrector, reverse-diffusion predictor,
+score network, surrogate gradient, per-step noise -- runs in ``dnag_pc_sample`` (``libdnag.so``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib, sde_lib
+from .cate import CATE, Workspace
+from .digcn_meta import MetaNeuralPredictor
+from .utils import MetaTestDataset
+
+DATA_PATH = "./data/transfer_nag"      # reference all_path.py
+
+_CORRECTORS = {}
+_PREDICTORS = {}
+
+
+def register_predictor(cls=None, *, name=None):
+    """A decorator for registering predictor classes (reference ``sampling.py:18-34``)."""
+
+    def _register(cls):
+        local_name = cls.__name__ if name is None else name
+        if local_name in _PREDICTORS:
+            raise ValueError(f'Already registered predictor with name: {local_name}')
+        _PREDICTORS[local_name] = cls
+        return cls
+
+    return _register if cls is None else _register(cls)
+
+
+def register_corrector(cls=None, *, name=None):
+    """A decorator for registering corrector classes (reference ``sampling.py:37-53``)."""
+
+    def _register(cls):
+        local_name = cls.__name__ if name is None else name
+        if local_name in _CORRECTORS:
+            raise ValueError(f'Already registered corrector with name: {local_name}')
+        _CORRECTORS[local_name] = cls
+        return cls
+
+    return _register if cls is None else _register(cls)
+
+
+def get_predictor(name):
+    return _PREDICTORS[name]
+
+
+def get_corrector(name):
+    return _CORRECTORS[name]
+
+
+# The registered classes only select which fused update the library runs: the update functions
+# themselves (reference ``sampling.py:189-263``) are device code in csrc/dnag_head.hip.h.
+@register_predictor(name='reverse_diffusion')
+class ReverseDiffusionPredictor:
+    """Reference ``sampling.py:203-213``; fused into ``head_out_kernel`` (EXIT_PREDICTOR)."""
+    fused = True
+
+
+@register_predictor(name='euler_maruyama')
+class EulerMaruyamaPredictor:
+    """Reference ``sampling.py:189-200``; a "next" row, not built yet."""
+    fused = False
+
+
+@register_predictor(name='none')
+class NonePredictor:
+    """Reference ``sampling.py:216-224``; not built."""
+    fused = False
+
+
+@register_corrector(name='langevin')
+class LangevinCorrector:
+    """Reference ``sampling.py:227-256``; ``head_out_kernel`` (EXIT_CORRECTOR) + ``corrector_update_kernel``."""
+    fused = True
+    enabled = 1
+
+
+@register_corrector(name='none')
+class NoneCorrector:
+    """Reference ``sampling.py:259-267``: identity."""
+    fused = True
+    enabled = 0
+
+
+def get_sampling_fn(config, sde, shape, inverse_scaler, eps, conditional=False, data_name='cifar10', num_sample=20):
+    """Create a sampling function (reference ``sampling.py:64-133``, same arguments)."""
+    sampler_name = config.sampling.method
+    if sampler_name.lower() == 'pc':
+        predictor = get_predictor(config.sampling.predictor.lower())
+        corrector = get_corrector(config.sampling.corrector.lower())
+        noise = config.sampling.noise if 'noise' in config.sampling else 'philox'
+        common = dict(sde=sde, shape=shape, predictor=predictor, corrector=corrector, inverse_scaler=inverse_scaler,
+                      snr=config.sampling.snr, n_steps=config.sampling.n_steps_each,
+                      probability_flow=config.sampling.probability_flow, continuous=config.training.continuous,
+                      denoise=config.sampling.noise_removal, eps=eps, device=config.device, noise=noise)
+        if not conditional:
+            return get_pc_sampler_nas(**common)
+        return get_pc_conditional_sampler_meta_nas(regress=config.sampling.regress, labels=config.sampling.labels,
+                                                   data_name=data_name, num_sample=num_sample, **common)
+    raise NotImplementedError(f"Sampler name {sampler_name} unknown.")
+
+
+class _PCSampler:
+    """State shared by the two sampler callables.  Besides the reference's call signature it has a
+    few attributes for tests and benchmarks: ``noise_tape`` (dict of device tensors ``x0 [B,N,V]``,
+    ``corrector [S,B,N,V]``, ``predictor [S,B,N,V]`` consumed in the reference's RNG order),
+    ``max_steps`` (run only the first steps of the time grid), ``record`` (keep per-step tensors in
+    ``last_record``), ``seed`` / ``stream_offset`` (Philox key and first element index of this shard)."""
+
+    def __init__(self, sde, shape, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow, continuous,
+                 denoise, eps, device, noise):
+        if not isinstance(sde, sde_lib.VPSDE):
+            raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
+        if not getattr(predictor, "fused", False):
+            raise NotImplementedError(f"predictor {predictor.__name__} is not built (only 'reverse_diffusion')")
+        if not getattr(corrector, "fused", False):
+            raise NotImplementedError(f"corrector {corrector.__name__} is not built (only 'langevin' and 'none')")
+        if probability_flow:
+            raise NotImplementedError("probability_flow=True is not built")
+        if not continuous:
+            raise NotImplementedError("only continuous=True is supported (SURVEY.md 5.2-6)")
+        if n_steps != 1 and corrector.enabled:
+            raise NotImplementedError("n_steps_each != 1 is not built (every shipped config uses 1)")
+        if noise not in ("philox", "torch"):
+            raise ValueError(f"config.sampling.noise={noise!r}: expected 'philox' or 'torch'")
+        self.sde, self.shape, self.corrector = sde, tuple(shape), corrector
+        self.inverse_scaler, self.snr, self.n_steps, self.denoise = inverse_scaler, snr, n_steps, denoise
+        self.eps, self.device, self.noise = eps, torch.device(device), noise
+        self.noise_tape: Optional[dict] = None
+        self.max_steps: Optional[int] = None
+        self.record = False
+        self.last_record: Optional[dict] = None
+        self.seed = 0
+        self.stream_offset = 0
+        self._ws = Workspace()
+        self._calls = 0
+
+    # ---------------------------------------------------------------------------------------------
+    def _run(self, score_model: CATE, mask, classifier=None, classifier_scale=None, task=None, labels='max'):
+        lib = _lib.load()
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("diffusionnag_amd samplers run on an MI355X only (config.device must be a cuda device)")
+        if not isinstance(score_model, CATE):
+            raise TypeError("score_model must be diffusionnag_amd.cate.CATE (create it with mutils.create_model)")
+        B, N, V = self.shape
+        S = self.sde.N if self.max_steps is None else int(self.max_steps)
+        sched = self.sde.schedule_table(self.eps, S)
+        score_model.eval()
+        cd = score_model.dims_c()
+        if (N, V) != (cd.max_node, cd.n_vocab):
+            raise ValueError(f"sampler shape {self.shape} does not match the score network ({cd.max_node}, {cd.n_vocab})")
+        m = torch.as_tensor(mask, dtype=torch.float32)
+        if m.dim() == 3:
+            m = m[0]                                                 # sampling.py:438 / :568
+        m = m.to(dev).contiguous()
+        args = _lib.PcArgsC()
+        keep = [sched, m]
+        args.cate_dims = C.pointer(cd)
+        args.cate_packed = _lib.ptr(score_model.packed(dev))
+        pd = None
+        if classifier is not None:
+            if not isinstance(classifier, MetaNeuralPredictor):
+                raise TypeError("classifier must be diffusionnag_amd.digcn_meta.MetaNeuralPredictor")
+            if classifier_scale is None:
+                raise ValueError("classifier_scale is required for guided sampling")
+            classifier.eval()
+            classifier.sample_state = True                           # sampling.py:561-562
+            classifier.D_mu = None
+            d_mu = classifier._dataset_embedding(task.to(dev), dev)
+            pd = classifier.dims_c()
+            args.pred_dims = C.pointer(pd)
+            args.pred_packed = _lib.ptr(classifier.packed(dev))
+            args.d_mu = _lib.ptr(d_mu)
+            args.classifier_scale = float(classifier_scale)
+            args.label_sign = 1.0 if labels == 'max' else -1.0
+            keep += [d_mu]
+        args.batch, args.n_steps = B, S
+        args.mask = _lib.ptr(m)
+        args.sched = sched.ctypes.data
+        args.snr = float(self.snr)
+        args.corrector = int(self.corrector.enabled)
+        # noise ------------------------------------------------------------------------------------
+        tape = self.noise_tape
+        if tape is None:
+            x0 = self.sde.prior_sampling(self.shape).to(dev)         # CPU generator, then H2D (sampling.py:436)
+            if self.noise == "torch":
+                # the reference draws eps then z with randn_like on the device generator, step by step
+                nc = torch.empty(S, B, N, V, device=dev)
+                npd = torch.empty(S, B, N, V, device=dev)
+                for i in range(S):
+                    if self.corrector.enabled:
+                        nc[i] = torch.randn_like(x0)
+                    npd[i] = torch.randn_like(x0)
+                tape = {"x0": x0, "corrector": nc, "predictor": npd}
+            else:
+                tape = {"x0": x0, "corrector": None, "predictor": None}
+        x0 = tape["x0"].to(dev, torch.float32).contiguous()
+        nc = tape.get("corrector")
+        npd = tape.get("predictor")
+        if (nc is None) != (npd is None):
+            raise ValueError("noise_tape needs both 'corrector' and 'predictor' or neither")
+        if nc is not None:
+            nc = nc.to(dev, torch.float32).contiguous()
+            npd = npd.to(dev, torch.float32).contiguous()
+            if nc.shape[0] < S or npd.shape[0] < S or tuple(nc.shape[1:]) != (B, N, V):
+                raise ValueError("noise_tape is shorter than the number of steps or has the wrong shape")
+        keep += [x0, nc, npd]
+        args.x0, args.noise_corr, args.noise_pred = _lib.ptr(x0), _lib.ptr(nc), _lib.ptr(npd)
+        self._calls += 1
+        args.seed = int(self.seed) + 0x9E3779B97F4A7C15 * self._calls & 0xFFFFFFFFFFFFFFFF if nc is None else int(self.seed)
+        args.stream_offset = int(self.stream_offset)
+        # outputs ----------------------------------------------------------------------------------
+        out = torch.empty(B, N, V, dtype=torch.float32, device=dev)
+        x_last = torch.empty_like(out)
+        x_mean = torch.empty_like(out)
+        args.x_out, args.x_last, args.x_mean_last = _lib.ptr(out), _lib.ptr(x_last), _lib.ptr(x_mean)
+        rec = None
+        if self.record:
+            names = ["rec_score_c", "rec_total_c", "rec_x_corr", "rec_score_p", "rec_total_p", "rec_x_mean", "rec_x_pred"]
+            if classifier is not None:
+                names += ["rec_cgrad_c", "rec_cgrad_p"]
+            rec = {n: torch.zeros(S, B, N, V, dtype=torch.float32, device=dev) for n in names}
+            rec["rec_step_size"] = torch.zeros(S, 3, dtype=torch.float32, device=dev)
+            for n, t in rec.items():
+                setattr(args, n, _lib.ptr(t))
+        nbytes = lib.dnag_workspace_bytes(C.byref(cd), C.byref(pd) if pd is not None else None, B, S)
+        ws = self._ws.get(nbytes, dev)
+        args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        args.stream = _lib.current_stream(dev)
+        with torch.cuda.device(dev):
+            rc = lib.dnag_pc_sample(C.byref(args))
+        _lib.check(rc, "dnag_pc_sample")
+        if classifier is not None:
+            classifier.sample_state = False                          # sampling.py:576
+        self.last_record = rec
+        del keep
+        kind = getattr(self.inverse_scaler, "dnag_kind", None)
+        if self.denoise and kind == "centered":
+            return out                                               # (x_mean + 1) / 2 from the exit kernel
+        raw = x_mean if self.denoise else x_last
+        return self.inverse_scaler(raw)
+
+
+class _PCUnconditional(_PCSampler):
+    def __call__(self, model, mask):
+        """Reference ``pc_sampler(model, mask)`` (``sampling.py:424-445``): returns
+        ``(samples, sde.N * (n_steps + 1), None)``."""
+        x = self._run(model, mask)
+        return x, self.sde.N * (self.n_steps + 1), None
+
+
+class _PCConditional(_PCSampler):
+    def __init__(self, *a, regress=True, labels='max', data_name='cifar10', num_sample=20, **k):
+        super().__init__(*a, **k)
+        if not regress:
+            raise NotImplementedError("classification guidance (regress=False) is not built")
+        assert labels in ['max', 'min']
+        self.labels = labels
+        # the reference opens the feature blob here (sampling.py:490-493); it is opened on first use instead
+        self.test_dataset = MetaTestDataset(data_path=DATA_PATH, data_name=data_name, num_sample=num_sample)
+
+    def __call__(self, score_model, mask, classifier, classifier_scale=None, task=None):
+        """Reference ``pc_conditional_sampler`` (``sampling.py:534-577``): returns the samples."""
+        if task is None:
+            task = self.test_dataset[0]
+        return self._run(score_model, mask, classifier, classifier_scale, task, self.labels)
+
+
+def get_pc_sampler_nas(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,
+                       continuous=False, denoise=True, eps=1e-3, device='cuda', noise='philox'):
+    """Reference ``sampling.py:380-447``."""
+    return _PCUnconditional(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow,
+                            continuous, denoise, eps, device, noise)
+
+
+def get_pc_conditional_sampler_meta_nas(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1,
+                                        probability_flow=False, continuous=False, denoise=True, eps=1e-5,
+                                        device='cuda', regress=True, labels='max', data_name='cifar10',
+                                        num_sample=20, noise='philox'):
+    """Reference ``sampling.py:450-579``."""
+    return _PCConditional(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow,
+                          continuous, denoise, eps, device, noise, regress=regress, labels=labels,
+                          data_name=data_name, num_sample=num_sample)

@@ -1,0 +1,170 @@
+/*
+ * dnag.h -- C ABI of the MI355X-native reverse-diffusion sampling hot path.
+ *
+ * Every entry point takes plain pointers and sizes.  Device pointers are HIP device
+ * addresses on the CURRENT device; `stream` is a hipStream_t passed as void*.  The caller
+ * owns every buffer; the library allocates no device memory.  All entry points return 0 on
+ * success and a negative code on error (DNAG_E_*); dnag_last_error() gives the message of
+ * the calling thread's last failure.  Nothing here synchronises the host with the device
+ * unless the comment says so.
+ *
+ * Reference citations are relative to /root/reference/NAS-Bench-201/.
+ */
+#ifndef DNAG_H
+#define DNAG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DNAG_E_ARG      (-1)   /* bad argument / unsupported shape */
+#define DNAG_E_WORKSPACE (-2)  /* workspace too small */
+#define DNAG_E_HIP      (-3)   /* a HIP call failed (message has hipGetErrorString) */
+
+/* Score network shape (CATE, models/cate.py:108-143; values: configs/tr_scorenet.py:60-101). */
+typedef struct dnag_cate_dims {
+    int32_t max_node;      /* N: 8 (NAS-Bench-201) or 20 (OFA) */
+    int32_t n_vocab;       /* V: 7 or 9 */
+    int32_t d_model;       /* 64 */
+    int32_t n_head;        /* 8 */
+    int32_t d_ff;          /* 128 */
+    int32_t n_layers;      /* 12 */
+    int32_t stagewise_pos; /* 0: PositionalEncoding_Cell, 1: _StageWise (cate.py:133-136) */
+} dnag_cate_dims;
+
+/* Surrogate shape (MetaNeuralPredictor, models/digcn_meta.py:56-107). */
+typedef struct dnag_pred_dims {
+    int32_t max_node;      /* 8 */
+    int32_t n_vocab;       /* graph_encoder.initial_hidden = 7 */
+    int32_t gcn_hidden;    /* 144 */
+    int32_t gcn_layers;    /* 4 */
+    int32_t linear_hidden; /* 128 */
+    int32_t hs;            /* 32 (512 in the pickled Transfer-NAG config) */
+    int32_t nz;            /* 56 */
+} dnag_pred_dims;
+
+int         dnag_abi_version(void);
+const char *dnag_last_error(void);
+
+/* ---- host-side weight packing (no device access) -------------------------------------------
+ * `state_flat` is the concatenation of the state_dict tensors in state_dict() order, fp32
+ * (models/cate.py:110-126, models/transformer.py:69-179).  `tables` are
+ * the two non-parameter constants the reference builds in its constructors:
+ *   CATE:      pos-enc table [max_node][d_model] (cate.py:211-248) then timestep frequencies
+ *              [d_model/2] (cate.py:363-368);
+ *   predictor: timestep frequencies [gcn_hidden/2] (digcn_meta.py:162-168).
+ * `packed` receives the kernel layout (LayerNorm affine folded into the following linear,
+ * DiGCN weights also stored transposed).  Sizes are in floats. */
+size_t dnag_cate_state_floats(const dnag_cate_dims *d);
+size_t dnag_cate_table_floats(const dnag_cate_dims *d);
+size_t dnag_cate_packed_floats(const dnag_cate_dims *d);
+int    dnag_cate_pack(const dnag_cate_dims *d, const float *state_flat, const float *tables, float *packed);
+
+/* Only the parameters used while sampling are consumed, in this order: gcn.l.weight1,
+ * gcn.l.weight2 (l = 0..L-1), fc1.weight, timeEmb1.{weight,bias}, timeEmb2.{weight,bias},
+ * pred_fc.0.{weight,bias}, pred_fc.2.{weight,bias} (the set-encoder stays in PyTorch and runs
+ * once per call, digcn_meta.py:150-156). */
+size_t dnag_pred_state_floats(const dnag_pred_dims *d);
+size_t dnag_pred_table_floats(const dnag_pred_dims *d);
+size_t dnag_pred_packed_floats(const dnag_pred_dims *d);
+int    dnag_pred_pack(const dnag_pred_dims *d, const float *state_flat, const float *tables, float *packed);
+
+/* Bytes of device workspace needed for a batch of `batch` graphs (`pd` may be NULL). */
+size_t dnag_workspace_bytes(const dnag_cate_dims *cd, const dnag_pred_dims *pd, int batch, int n_steps);
+
+/* ---- score network forward ------------------------------------------------------------------
+ * Replaces CATE.forward(X, time_cond, maskX) (models/cate.py:145-164, eval mode).
+ * x [batch][N][V]; time_cond [batch] if time_stride==1, [1] if 0; mask [batch][N][N] if
+ * mask_stride==1, [1][N][N] if 0 (query i sees key j iff mask[i][j]!=0, transformer.py:16);
+ * out [batch][N][V].  `concat_out` (may be NULL) receives the all-layer concat [batch*N][L*d]
+ * (cate.py:83-86), `attn0_out` (may be NULL) layer-0 attention probabilities [batch][H][N][N]. */
+int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, const float *x,
+                      const float *time_cond, int time_stride, const float *mask, int mask_stride,
+                      float *out, float *concat_out, float *attn0_out, int batch,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- surrogate forward + guidance gradient ---------------------------------------------------
+ * Replaces MetaNeuralPredictor.forward with cached D_mu (digcn_meta.py:109-159) and
+ * get_classifier_grad_fn (models/utils.py:126-147, regress=True): y [batch] (may be NULL) and
+ * grad [batch][N][V] = d(sum_b y_b)/dx (may be NULL; caller applies the 'min' sign).
+ * d_mu [nz] is the dataset embedding (digcn_meta.py:131-139) computed once per call. */
+int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *packed, const float *x,
+                           const float *time_cond, int time_stride, const float *mask, int mask_stride,
+                           const float *d_mu, float *y, float *grad, int batch,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- predictor-corrector sampler -------------------------------------------------------------
+ * Replaces the loops of pc_sampler (sampling.py:424-445) and pc_conditional_sampler
+ * (sampling.py:534-577) for ReverseDiffusionPredictor (sampling.py:203-213) + LangevinCorrector
+ * (sampling.py:227-256) on a VPSDE (sde_lib.py:145-211), continuous=True, probability_flow=False.
+ *
+ * `sched` is a HOST array [n_steps][DNAG_SCHED_COLS] built by the host mirror of VPSDE
+ * (diffusionnag_amd/sde_lib.py) with the reference's own fp32 arithmetic. */
+#define DNAG_SCHED_COLS 8
+#define DNAG_SCHED_LABEL 0  /* 999 * t_i                       (models/utils.py:93)  */
+#define DNAG_SCHED_STD   1  /* marginal_prob std at t_i        (sde_lib.py:179-188)  */
+#define DNAG_SCHED_ALPHA 2  /* alphas[k_i]                     (sampling.py:238-240) */
+#define DNAG_SCHED_SQRTA 3  /* sqrt(alphas[k_i])               (sde_lib.py:203)      */
+#define DNAG_SCHED_G     4  /* sqrt(discrete_betas[k_i])       (sde_lib.py:204)      */
+#define DNAG_SCHED_G2    5  /* G * G in fp32                   (sde_lib.py:122)      */
+#define DNAG_SCHED_T     6  /* t_i                                                   */
+
+typedef struct dnag_pc_args {
+    /* networks */
+    const dnag_cate_dims *cate_dims;
+    const float *cate_packed;          /* device */
+    const dnag_pred_dims *pred_dims;   /* NULL: unconditional */
+    const float *pred_packed;          /* device, or NULL */
+    const float *d_mu;                 /* device [nz], or NULL */
+    float classifier_scale;            /* sampling.py:505 */
+    float label_sign;                  /* +1 for labels='max', -1 for 'min' (models/utils.py:136-139) */
+    /* problem */
+    int32_t batch;
+    const float *mask;                 /* device [N][N] (mask[0] of the caller's tensor, sampling.py:438) */
+    const float *sched;                /* HOST [n_steps][DNAG_SCHED_COLS] */
+    int32_t n_steps;                   /* number of PC steps to run (sde.N for a full trajectory) */
+    float snr;                         /* sampling.py:251 */
+    int32_t corrector;                 /* 1: LangevinCorrector, 0: NoneCorrector */
+    /* noise: tape mode if noise_corr/noise_pred != NULL ([n_steps][batch][N][V] each, device,
+     * the order of randn_like at sampling.py:247 and :210); otherwise on-device Philox4x32-10 +
+     * Box-Muller keyed by (seed, stream_offset + element index, step). */
+    const float *x0;                   /* device [batch][N][V] prior sample (sampling.py:436) or NULL (Philox) */
+    const float *noise_corr;
+    const float *noise_pred;
+    uint64_t seed;
+    uint64_t stream_offset;            /* first global element index of this shard (multi-GPU) */
+    /* outputs (device) */
+    float *x_out;                      /* [batch][N][V] inverse_scaler(x_mean_last) = (x_mean+1)/2 (sampling.py:445) */
+    float *x_last;                     /* optional: noisy x after the last predictor step, raw scale */
+    float *x_mean_last;                /* optional: x_mean of the last predictor step, raw scale */
+    /* optional per-step records for parity tests (device, may be NULL): [n_steps][batch][N][V] */
+    float *rec_score_c, *rec_total_c, *rec_x_corr, *rec_score_p, *rec_total_p, *rec_x_mean, *rec_x_pred;
+    float *rec_cgrad_c, *rec_cgrad_p;
+    float *rec_step_size;              /* [n_steps][3]: grad_norm, noise_norm, step_size */
+    /* workspace */
+    void *workspace;
+    size_t workspace_bytes;
+    void *stream;
+} dnag_pc_args;
+
+int dnag_pc_sample(const dnag_pc_args *args);
+
+/* ---- exit: threshold (utils.py:244-262) --------------------------------------------------------
+ * q[i] = x[i] >= 0.5 ? 1 : 0, n elements, device pointers. */
+int dnag_quantize(const float *x, float *q, size_t n, void *stream);
+
+/* ---- kernel timing for bench.py ----------------------------------------------------------------
+ * While enabled, every `every`-th launch of the head GEMM (the dominant kernel) is bracketed by a
+ * pair of HIP events on the launch stream.  dnag_timing_read() synchronises those events and
+ * returns the number of timed launches, their mean duration (ms) and the FLOPs of one launch. */
+int dnag_timing_begin(int every, int max_samples);
+int dnag_timing_read(int *n_samples, double *mean_ms, double *flops_per_launch);
+int dnag_timing_end(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DNAG_H */
