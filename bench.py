@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Benchmark of the sampling hot path: guided NAS-Bench-201 architecture samples/s for the FULL reverse
+SDE (BASELINE.json configs[1]: predictor-guided sampling, batch 4096 per GPU, N = 1000 PC steps =
+2000 score evaluations + 2000 guidance gradients per sample, VPSDE + reverse_diffusion + langevin).
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete trajectory of one batch (weights, mask and D_mu resident in HBM, noise drawn
+on the device by the Philox generator inside the timed region, as the reference draws it inside its
+loop).  N > 1: every rank samples its own batch of the same size (weak scaling), no collective during
+sampling, one RCCL all_gather of the samples at the end of each step.  Rank 0 prints ONE JSON line.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from diffusionnag_amd import _lib, mutils, sampling, sde_lib, synthetic, utils  # noqa: E402
+from diffusionnag_amd import cate as _cate, digcn_meta as _dm  # noqa: E402,F401
+from diffusionnag_amd import distributed as D  # noqa: E402
+from diffusionnag_amd.specs import CateDims, PredictorDims  # noqa: E402
+
+# algorithmic FLOPs (2 per MAC) of one guided NB201 sample: SURVEY.md section 8d
+FLOP_PER_SAMPLE = 136.3e9
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def score_config(device):
+    d = CateDims()
+    ge = Cfg(n_layers=d.n_layers, d_model=d.d_model, n_head=d.n_head, d_ff=d.d_ff, dropout=0.1, n_vocab=d.n_vocab)
+    return Cfg(device=device, data=Cfg(name="NASBench201", max_node=8, n_vocab=7, centered=True),
+               model=Cfg(name="CATE", nonlinearity="swish", dropout=0.1, pos_enc_type=2, graph_encoder=ge),
+               training=Cfg(continuous=True),
+               sampling=Cfg(method="pc", predictor="reverse_diffusion", corrector="langevin", snr=0.16, n_steps_each=1,
+                            probability_flow=False, noise_removal=True, regress=True, labels="max"))
+
+
+def predictor_config(device):
+    d = PredictorDims()
+    ge = Cfg(initial_hidden=7, gcn_hidden=d.gcn_hidden, gcn_layers=d.gcn_layers, linear_hidden=d.linear_hidden)
+    return Cfg(device=device, model=Cfg(name="MetaNeuralPredictor", nonlinearity="swish", input_type="DA", hs=d.hs,
+                                        nz=d.nz, num_sample=d.num_sample, graph_encoder=ge))
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle (PyTorch-eager CPU restatement of the reference, validated against its golden vectors)
+    timed on this box's host cores on a bounded sample of the same workload: guided NB201 PC steps
+    at B=256, extrapolated to the 1000 steps of a trajectory (the cost of a step does not depend on t)."""
+    from oracle import dnag_oracle as O
+    B = 256
+    sd = synthetic.cate_state_dict(CateDims(), seed=0)
+    sdp = synthetic.predictor_state_dict(PredictorDims(), seed=1)
+    D_mu = O.set_encode(sdp, synthetic.synthetic_task(10, 20, seed=2))
+    sde = O.VPSDE(0.1, 20.0, 1000)
+    mask = O.floyed(O.nb201_adj())
+    kw = dict(pred_sd=sdp, D_mu=D_mu, classifier_scale=10000.0)
+    tape = synthetic.noise_tape(16, (B, 8, 7), 1)
+    O.pc_sample(sd, sde, mask, tape, n_steps=3, **kw)          # warm-up (oneDNN primitive creation)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds and steps < 400:
+        O.pc_sample(sd, sde, mask, tape, n_steps=8, **kw)
+        steps += 8
+    dt = time.perf_counter() - t0
+    return {"value": B / (dt / steps * 1000.0), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} guided PC steps (2 score evals + 2 guidance grads each) at B={B} in {dt:.1f} s, "
+                      f"x1000 steps per trajectory"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--sde-steps", type=int, default=1000, help="PC steps per trajectory (1000 = the full reverse SDE)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank, world, local = D.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B = a.batch_per_gpu
+    total = B * world
+
+    cfg = score_config(dev)
+    model = mutils.create_model(cfg)
+    model.load_state_dict(synthetic.cate_state_dict(CateDims(), seed=0))
+    clf = mutils.create_model(predictor_config(dev))
+    clf.load_state_dict(synthetic.predictor_state_dict(PredictorDims(), seed=1))
+    task = synthetic.synthetic_task(10, 20, seed=2).to(dev)
+    mask = utils.aug_mask(utils.nb201_adj())[0].to(dev)          # Floyd closure, as generate_archs_meta builds it
+    sde = sde_lib.VPSDE(beta_min=0.1, beta_max=20.0, N=1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3, conditional=True)
+    if a.sde_steps != 1000:
+        fn.max_steps = a.sde_steps                               # debugging only: the reported metric needs 1000
+    start, _ = D.shard_batch(total, rank, world)
+    D.configure_sampler_shard(fn, start, 8, 7, seed=1234)
+    torch.manual_seed(1000 + rank)                               # x0 is drawn on the CPU generator, like the reference
+
+    def step():
+        x = fn(model, mask, clf, classifier_scale=10000.0, task=task)
+        return D.gather_samples(x, total)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        out = step()
+    lib = _lib.load()
+    _lib.check(lib.dnag_timing_begin(16, 2048), "dnag_timing_begin")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    import ctypes as C
+    n_s, mean_ms, flops = C.c_int(0), C.c_double(0.0), C.c_double(0.0)
+    _lib.check(lib.dnag_timing_read(C.byref(n_s), C.byref(mean_ms), C.byref(flops)), "dnag_timing_read")
+    lib.dnag_timing_end()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    finite = bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        value = total * a.steps / dt
+        achieved = flops.value / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
+        line = {
+            "metric": "guided arch samples/sec (full reverse SDE), NB201", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: NAS-Bench-201 predictor-guided sampling (meta-predictor gradient), "
+                                   f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
+                                   "snr 0.16, classifier_scale 1e4, Floyd-closure mask, random-init weights (seeded), "
+                                   "Philox noise on device",
+                       "batch_per_gpu": B, "global_batch": total, "pc_steps": a.sde_steps,
+                       "score_evals_per_sample": 2 * a.sde_steps, "parallelism": f"batch-shard x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_bias_act_kernel<true,1> (final.linears.1, M x 1536 x 1536, fp32 MFMA)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value},
+            "whole_path_tflops": value * FLOP_PER_SAMPLE * (a.sde_steps / 1000.0) / 1e12 / world,
+            "whole_path_frac_of_f32_mfma_peak": value * FLOP_PER_SAMPLE * (a.sde_steps / 1000.0) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+            "outputs_finite": finite,
+        }
+        if not a.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,309 @@
+"""Parity of the HIP path (through the C ABI in libdnag.so) with the golden vectors captured from the
+reference (tests/golden/*.npz) and with the CPU oracle on seeded inputs.  Needs an MI355X.
+
+Tolerances (fp32 path, different summation order than the CPU reference): single evaluations
+5e-6 of the tensor's max; teacher-free trajectories grow that error with the trajectory's own
+sensitivity, so later steps are checked to 2e-4 of the state's max, and the discretised
+architectures (threshold at 0.5) must match bit for bit."""
+
+import numpy as np
+import pytest
+import torch
+
+from diffusionnag_amd import cate as _cate, digcn_meta as _dm  # noqa: F401  (register the models)
+from diffusionnag_amd import mutils, sampling, sde_lib, synthetic, utils
+from diffusionnag_amd.specs import CateDims, PredictorDims
+from tests.helpers import golden, predictor_config, score_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, rel, what=""):
+    a = np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, np.float64)
+    b = np.asarray(b.detach().cpu() if torch.is_tensor(b) else b, np.float64)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    assert np.isfinite(a).all(), f"{what}: non-finite values"
+    e = np.abs(a - b).max()
+    scale = np.abs(b).max()
+    assert e <= rel * scale + 1e-30, f"{what}: max|err| {e:.3e} > {rel:.1e} * {scale:.3e}"
+
+
+def make_score(dims, seed, preset="default", perturb=False):
+    m = mutils.create_model(score_config(dims, DEV))
+    m.load_state_dict(synthetic.cate_state_dict(dims, seed=seed, preset=preset, perturb_norms=perturb))
+    return m.eval()
+
+
+def make_pred(seed=1, hs=32):
+    d = PredictorDims(hs=hs)
+    m = mutils.create_model(predictor_config(d, DEV))
+    m.load_state_dict(synthetic.predictor_state_dict(d, seed=seed))
+    return m.eval()
+
+
+# ------------------------------------------------------------------------------------------------
+# single evaluations against the reference's outputs
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mname", ["raw", "closure"])
+def test_cate_forward_nb201_golden(mname):
+    g = golden(f"cate_fwd_nb201_{mname}")
+    model = make_score(CateDims(), int(g["seed"]), perturb=True)
+    X = torch.from_numpy(g["X"]).to(DEV)
+    m = torch.from_numpy(g["mask"]).to(DEV).unsqueeze(0).repeat(X.shape[0], 1, 1)
+    out, concat, attn0 = model(X, torch.from_numpy(g["time_cond"]).to(DEV), m, return_concat=True, return_attn0=True)
+    close(out, g["out"], 5e-6, "out")
+    close(concat, g["concat"], 5e-6, "concat")
+    close(attn0, g["attn0"], 2e-6, "attn0")
+    if mname == "raw":   # fully masked sink row attends uniformly
+        assert np.allclose(attn0[:, :, 7, :].cpu().numpy(), 0.125)
+    # same mask passed once (mask_stride 0) gives the same bits
+    out1 = model(X, torch.from_numpy(g["time_cond"]).to(DEV), m[:1])
+    assert torch.equal(out, out1)
+
+
+def test_cate_forward_ofa_golden():
+    g = golden("cate_fwd_ofa_chain")
+    dims = CateDims(max_node=20, n_vocab=9, stagewise_pos=True)
+    model = make_score(dims, int(g["seed"]), perturb=True)
+    X = torch.from_numpy(g["X"]).to(DEV)
+    m = torch.from_numpy(g["mask"]).to(DEV).unsqueeze(0).repeat(X.shape[0], 1, 1)
+    close(model(X, torch.from_numpy(g["time_cond"]).to(DEV), m), g["out"], 5e-6, "out")
+
+
+@pytest.mark.parametrize("mname", ["raw", "closure"])
+def test_predictor_and_guidance_gradient_golden(mname):
+    g = golden(f"predictor_nb201_{mname}")
+    clf = make_pred(int(g["seed"]))
+    task = synthetic.synthetic_task(10, 20, seed=int(g["task_seed"])).to(DEV)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    X = torch.from_numpy(g["X"]).to(DEV)
+    B = X.shape[0]
+    m = torch.from_numpy(g["mask"]).to(DEV).unsqueeze(0).repeat(B, 1, 1)
+    clf.sample_state, clf.D_mu = True, None
+    gmax = mutils.get_classifier_grad_fn(sde, clf, train=False, continuous=True, regress=True, labels="max")
+    gmin = mutils.get_classifier_grad_fn(sde, clf, train=False, continuous=True, regress=True, labels="min")
+    for i, tval in enumerate(g["t"]):
+        t = torch.ones(B, device=DEV) * float(tval)
+        y = clf(X, t * 999, m, task=task.repeat(B, 1, 1))
+        assert y.shape == (B, 1)
+        close(y, g["y"][i], 5e-6, "y")
+        gr = gmax(X, t, m, task=task.repeat(B, 1, 1))
+        close(gr, g["grad"][i], 5e-6, "grad")
+        assert torch.equal(gmin(X, t, m, task=task), -gr)
+    close(clf.D_mu[0], g["D_mu"], 5e-6, "D_mu")
+    clf.sample_state = False
+
+
+def test_score_fn_wrapper_matches_oracle():
+    from oracle import dnag_oracle as O
+    sd = synthetic.cate_state_dict(CateDims(), seed=4, perturb_norms=True)
+    model = make_score(CateDims(), 4, perturb=True)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    rs = np.random.RandomState(8)
+    B = 37     # not a multiple of any block size: ragged tail blocks
+    X = torch.from_numpy(rs.standard_normal((B, 8, 7)).astype(np.float32))
+    t = torch.from_numpy(rs.uniform(1e-3, 1, B).astype(np.float32))
+    masks = torch.from_numpy((rs.uniform(0, 1, (B, 8, 8)) < 0.4).astype(np.float32))
+    ref = O.score_fn(sd, O.VPSDE(0.1, 20.0, 1000), X, t, masks)
+    fn = mutils.get_score_fn(sde, model, train=False, continuous=True)
+    close(fn(X.to(DEV), t.to(DEV), masks.to(DEV)), ref, 1e-5, "score")
+
+
+def test_predictor_hs512_and_ragged_batch_matches_oracle():
+    from oracle import dnag_oracle as O
+    d = PredictorDims(hs=512)
+    sdp = synthetic.predictor_state_dict(d, seed=9)
+    clf = make_pred(9, hs=512)
+    task = synthetic.synthetic_task(10, 20, seed=3)
+    D_mu = O.set_encode(sdp, task)
+    rs = np.random.RandomState(10)
+    B = 13
+    X = torch.from_numpy(rs.standard_normal((B, 8, 7)).astype(np.float32))
+    t = torch.from_numpy(rs.uniform(1e-3, 1, B).astype(np.float32))
+    masks = torch.from_numpy((rs.uniform(0, 1, (B, 8, 8)) < 0.3).astype(np.float32))
+    ref_y = O.predictor_forward(sdp, X, t * 999, masks, D_mu)
+    ref_g = O.classifier_grad(sdp, X, t, masks, D_mu)
+    y = clf(X.to(DEV), (t * 999).to(DEV), masks.to(DEV), task=task.to(DEV))
+    gr = clf.input_grad(X.to(DEV), (t * 999).to(DEV), masks.to(DEV), task=task.to(DEV))
+    close(y, ref_y, 1e-5, "y")
+    close(gr, ref_g, 1e-5, "grad")
+
+
+# ------------------------------------------------------------------------------------------------
+# sampler trajectories against the reference's recorded runs (injected noise tape)
+# ------------------------------------------------------------------------------------------------
+def run_sampler(g, guided, record=True):
+    B, S = int(g["B"]), int(g["n_run"])
+    cfg = score_config(CateDims(), DEV)
+    model = make_score(CateDims(), int(g["seed"]), preset=str(g["preset"]))
+    sde = sde_lib.VPSDE(0.1, float(g["beta_max"]), int(g["sde_N"]))
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), float(g["eps"]), conditional=guided)
+    tape = synthetic.noise_tape(S, (B, 8, 7), int(g["tape_seed"]))
+    fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
+    fn.max_steps = S
+    fn.record = record
+    mask = torch.from_numpy(g["mask"])
+    if guided:
+        final = fn(model, mask, make_pred(1), classifier_scale=float(g["classifier_scale"]),
+                   task=synthetic.synthetic_task(10, 20, seed=2))
+    else:
+        final, nfe, extra = fn(model, mask.unsqueeze(0))
+        assert nfe == sde.N * 2 and extra is None
+    return final, fn.last_record
+
+
+@pytest.mark.parametrize("name,guided", [("pc_uncond_nb201_n1000_first8", False), ("pc_guided_nb201_n1000_first8", True)])
+def test_pc_first_steps_random_init(name, guided):
+    g = golden(name)
+    _, r = run_sampler(g, guided)
+    for i in range(int(g["n_run"])):
+        close(r["rec_score_c"][i], g["score_c"][i], 1e-5, f"score_c[{i}]")
+        close(r["rec_score_p"][i], g["score_p"][i], 1e-5, f"score_p[{i}]")
+        close(r["rec_x_corr"][i], g["x_corr"][i], 5e-6, f"x_corr[{i}]")
+        close(r["rec_x_mean"][i], g["x_mean"][i], 5e-6, f"x_mean[{i}]")
+        close(r["rec_x_pred"][i], g["x_pred"][i], 5e-6, f"x_pred[{i}]")
+        if guided:
+            close(r["rec_cgrad_c"][i], g["cgrad_c"][i], 1e-5, f"cgrad_c[{i}]")
+            close(r["rec_cgrad_p"][i], g["cgrad_p"][i], 1e-5, f"cgrad_p[{i}]")
+
+
+@pytest.mark.parametrize("name,guided", [("pc_uncond_nb201_contractive_n100", False), ("pc_guided_nb201_contractive_n100", True)])
+def test_pc_full_trajectory_contractive(name, guided):
+    g = golden(name)
+    final, r = run_sampler(g, guided)
+    for i in (0, 1, 10, 50, 99):
+        close(r["rec_x_pred"][i], g["x_pred"][i], 2e-4, f"x_pred[{i}]")
+        close(r["rec_score_p"][i], g["score_p"][i], 2e-4, f"score_p[{i}]")
+    close(final, g["final"], 2e-4, "final")
+    q = np.stack(utils.quantize(final))
+    assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
+
+
+def test_pc_full_n1000_guided_contractive():
+    """The real schedule (N=1000: 2000 guided evaluations) end to end, B=4."""
+    g = golden("pc_guided_nb201_contractive_n1000")
+    final, _ = run_sampler(g, True, record=False)
+    close(final, g["final"], 2e-4, "final")
+    q = np.stack(utils.quantize(final))
+    assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
+
+
+def test_tape_run_is_reproducible_and_batch_size_independent_per_eval():
+    """Same tape twice -> identical bits (fixed reduction orders, no atomics)."""
+    g = golden("pc_uncond_nb201_n1000_first8")
+    a, _ = run_sampler(g, False)
+    b, _ = run_sampler(g, False)
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE config 2 shapes) and the on-device noise source
+# ------------------------------------------------------------------------------------------------
+def test_full_batch_guided_steps_match_oracle_on_a_slice():
+    """B=4096 guided, 2 PC steps with an injected tape: per-evaluation quantities of a 16-graph slice
+    are checked against the oracle teacher-forced on the recorded states (the Langevin step size
+    couples the whole batch, so it is recomputed from the recorded full-batch totals)."""
+    from oracle import dnag_oracle as O
+    B, S = 4096, 2
+    cfg = score_config(CateDims(), DEV)
+    sd = synthetic.cate_state_dict(CateDims(), seed=0)
+    sdp = synthetic.predictor_state_dict(PredictorDims(), seed=1)
+    model, clf = make_score(CateDims(), 0), make_pred(1)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3, conditional=True)
+    tape = synthetic.noise_tape(S, (B, 8, 7), 21)
+    fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
+    fn.max_steps, fn.record = S, True
+    mask = utils.aug_mask(utils.nb201_adj())[0]
+    task = synthetic.synthetic_task(10, 20, seed=2)
+    fn(model, mask, clf, classifier_scale=10000.0, task=task)
+    r = {k: v.cpu() for k, v in fn.last_record.items()}
+    osde = O.VPSDE(0.1, 20.0, 1000)
+    ts = O.timesteps(osde, 1e-3)
+    D_mu = O.set_encode(sdp, task)
+    sl = slice(100, 116)
+    mB = mask.unsqueeze(0).repeat(16, 1, 1)
+    x_in = tape["x0"]
+    for i in range(S):
+        vec_t = torch.ones(16) * ts[i]
+        s = O.score_fn(sd, osde, x_in[sl], vec_t, mB)
+        cg = O.classifier_grad(sdp, x_in[sl], vec_t, mB, D_mu)
+        close(r["rec_score_c"][i][sl], s, 1e-5, f"score_c[{i}]")
+        close(r["rec_cgrad_c"][i][sl], cg, 1e-5, f"cgrad_c[{i}]")
+        close(r["rec_total_c"][i][sl], s + 10000.0 * cg, 1e-5, f"total_c[{i}]")
+        # step size from the full-batch totals (sampling.py:249-252)
+        gn = torch.norm(r["rec_total_c"][i].reshape(B, -1), dim=-1).mean()
+        nn_ = torch.norm(tape["corrector"][i].reshape(B, -1), dim=-1).mean()
+        k = osde.timestep_index(ts[i:i + 1])
+        step = (0.16 * nn_ / gn) ** 2 * 2 * osde.alphas[k][0]
+        close(r["rec_step_size"][i], torch.stack([gn, nn_, step]), 2e-6, f"step_size[{i}]")
+        x_c = x_in + step * r["rec_total_c"][i] + torch.sqrt(step * 2) * tape["corrector"][i]
+        close(r["rec_x_corr"][i], x_c, 2e-6, f"x_corr[{i}]")
+        x_c = r["rec_x_corr"][i]
+        s2 = O.score_fn(sd, osde, x_c[sl], vec_t, mB)
+        close(r["rec_score_p"][i][sl], s2, 1e-5, f"score_p[{i}]")
+        x_in = r["rec_x_pred"][i]
+
+
+def test_philox_noise_statistics_and_determinism():
+    B = 4096
+    cfg = score_config(CateDims(), DEV)
+    model = make_score(CateDims(), 0, preset="contractive")
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3)
+    fn.max_steps, fn.record = 1, True
+    torch.manual_seed(3)
+    fn(model, utils.nb201_adj().unsqueeze(0))
+    r = fn.last_record
+    # recover the predictor noise z = (x_pred - x_mean) / G of step 0
+    G = float(sde.schedule_table(1e-3, 1)[0][4])
+    z = ((r["rec_x_pred"][0] - r["rec_x_mean"][0]) / G).double().cpu().numpy().ravel()
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02
+    assert abs((z ** 4).mean() - 3.0) < 0.2                   # kurtosis of a normal
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 0.02
+    # noise_norm recorded by the corrector is the mean norm of 56 standard normals: ~ sqrt(56 - 1/2)
+    assert abs(float(r["rec_step_size"][0, 1]) - np.sqrt(55.5)) < 0.1
+
+
+def test_noise_torch_mode_matches_tape_of_same_generator():
+    """config.sampling.noise='torch' draws eps, z with torch.randn_like in the reference's order."""
+    B, S = 8, 3
+    cfg = score_config(CateDims(), DEV)
+    cfg.sampling["noise"] = "torch"
+    model = make_score(CateDims(), 0)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3)
+    fn.max_steps = S
+    torch.manual_seed(11)
+    a = fn(model, utils.nb201_adj().unsqueeze(0))[0]
+    torch.manual_seed(11)
+    x0 = torch.randn(B, 8, 7).to(DEV)
+    nc, npd = [], []
+    for _ in range(S):
+        nc.append(torch.randn_like(x0))
+        npd.append(torch.randn_like(x0))
+    fn2 = sampling.get_sampling_fn(score_config(CateDims(), DEV), sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3)
+    fn2.max_steps = S
+    fn2.noise_tape = {"x0": x0, "corrector": torch.stack(nc), "predictor": torch.stack(npd)}
+    b = fn2(model, utils.nb201_adj().unsqueeze(0))[0]
+    assert torch.equal(a, b)
+
+
+def test_none_corrector_and_error_paths():
+    cfg = score_config(CateDims(), DEV)
+    cfg.sampling["corrector"] = "none"
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (4, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3)
+    fn.max_steps = 2
+    out = fn(make_score(CateDims(), 0), utils.nb201_adj().unsqueeze(0))[0]
+    assert out.shape == (4, 8, 7) and torch.isfinite(out).all()
+    with pytest.raises(RuntimeError):      # CPU tensors never silently fall back
+        make_score(CateDims(), 0)(torch.zeros(2, 8, 7), torch.zeros(2), torch.zeros(2, 8, 8))
+
+
+def test_quantize_device_threshold():
+    x = torch.tensor([[[0.5, 0.49999997, -1.0, 2.0, 0.0, 0.75, 0.25]] * 8], device=DEV)
+    q = utils.quantize(x)
+    assert len(q) == 1 and q[0].shape == (8, 7)
+    assert np.array_equal(q[0][0], np.array([1, 0, 0, 1, 0, 1, 0], np.float32))

@@ -1,0 +1,221 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, host-side weight packing,
+the schedule table, the reference-shaped host interface and its error behaviour, and the
+world_size-2 shard/gather path on gloo.  No kernel is launched here."""
+
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from diffusionnag_amd import _lib, mutils, sampling, sde_lib, synthetic, utils
+from diffusionnag_amd import cate as _cate, digcn_meta as _dm  # noqa: F401
+from diffusionnag_amd import distributed as D
+from diffusionnag_amd.specs import CateDims, PredictorDims, cate_param_spec, n_params, predictor_param_spec
+from oracle import dnag_oracle as O
+from tests.helpers import predictor_config, score_config
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    assert lib.dnag_abi_version() == 1
+    header = open(os.path.join(REPO, "include", "dnag.h")).read()
+    declared = set(re.findall(r"\b(dnag_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_layout_matches_header_field_order():
+    header = open(os.path.join(REPO, "include", "dnag.h")).read()
+    body = header[header.index("typedef struct dnag_pc_args {"):header.index("} dnag_pc_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    body = body[body.index("{") + 1:]
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl or decl.startswith("typedef"):
+            continue
+        for part in decl.split(","):
+            names.append(re.sub(r"[\*\s]", " ", part).split()[-1])
+    assert names == [f[0] for f in _lib.PcArgsC._fields_]
+
+
+def test_sizes_and_arg_errors():
+    lib = _lib.load()
+    d = _lib.CateDimsC(8, 7, 64, 8, 128, 12, 0)
+    p = _lib.PredDimsC(8, 7, 144, 4, 128, 32, 56)
+    assert lib.dnag_cate_state_floats(C.byref(d)) == n_params(cate_param_spec(CateDims())) == 3989575
+    spec = {k: s for k, s, _ in predictor_param_spec(PredictorDims())}
+    used = [k for k in spec if k.startswith(("gcn.", "fc1.", "timeEmb", "pred_fc."))]
+    assert lib.dnag_pred_state_floats(C.byref(p)) == sum(int(np.prod(spec[k])) for k in used)
+    assert lib.dnag_workspace_bytes(C.byref(d), C.byref(p), 4096, 1000) > 4096 * 8 * (768 + 2 * 1536) * 4
+    bad = _lib.CateDimsC(9, 7, 64, 8, 128, 12, 0)
+    buf = torch.zeros(16)
+    rc = lib.dnag_cate_pack(C.byref(bad), buf.data_ptr(), buf.data_ptr(), buf.data_ptr())
+    assert rc == -1 and b"unsupported graph shape" in lib.dnag_last_error()
+    with pytest.raises(RuntimeError, match="unsupported graph shape"):
+        _lib.check(rc, "dnag_cate_pack")
+    args = _lib.PcArgsC()
+    assert lib.dnag_pc_sample(C.byref(args)) == -1          # NULL dims rejected before any launch
+
+
+def test_cate_pack_folds_layernorm_into_linear():
+    dims = CateDims()
+    model = mutils.create_model(score_config(dims, "cpu"))
+    sd = synthetic.cate_state_dict(dims, seed=0, perturb_norms=True)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model.load_state_dict(sd)
+    packed = model._pack_host(model._state_flat().contiguous()).numpy().astype(np.float64)
+    # layout constants restated from csrc/dnag_common.h
+    d, V, dff = 64, 7, 128
+    layer0 = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d
+    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d
+    rs = np.random.RandomState(0)
+    h = rs.standard_normal((5, d))
+    for l in (0, 7):
+        base = layer0 + l * stride
+        Wqkv = packed[base: base + 3 * d * d].reshape(3 * d, d)
+        bqkv = packed[base + 3 * d * d: base + 3 * d * d + 3 * d]
+        p = f"graph_encoder.encoder_f.layers.{l}.self_attn"
+        g, b = sd[p + ".norm.weight"].double().numpy(), sd[p + ".norm.bias"].double().numpy()
+        xhat = (h - h.mean(1, keepdims=True)) / np.sqrt(h.var(1, keepdims=True) + 1e-5)
+        for j in range(3):
+            W = sd[p + f".attn.linears.{j}.weight"].double().numpy()
+            bb = sd[p + f".attn.linears.{j}.bias"].double().numpy()
+            ref = (xhat * g + b) @ W.T + bb
+            got = xhat @ Wqkv[j * d:(j + 1) * d].T + bqkv[j * d:(j + 1) * d]
+            assert np.abs(ref - got).max() < 1e-6
+    # head weights land verbatim
+    f0 = layer0 + 12 * stride
+    assert np.array_equal(packed[f0: f0 + 1536 * 768].astype(np.float32), sd["final.linears.0.weight"].numpy().ravel())
+    # derived tables = the oracle's restatement of the reference constructors
+    tail = packed[-(8 * 64 + 32):]
+    assert np.allclose(tail[: 8 * 64], O.positional_table(8, 64, False).numpy().ravel(), atol=0)
+    assert np.allclose(tail[8 * 64:], _cate.timestep_frequencies(64).numpy(), atol=0)
+
+
+def test_predictor_pack_transposes():
+    d = PredictorDims()
+    clf = mutils.create_model(predictor_config(d, "cpu"))
+    sdp = synthetic.predictor_state_dict(d, seed=1)
+    assert list(clf.state_dict().keys()) == list(sdp.keys())
+    clf.load_state_dict(sdp)
+    packed = clf._pack_host(clf._state_flat().contiguous()).numpy()
+    g = 144
+    w1_0 = packed[: 7 * g].reshape(7, g)
+    assert np.array_equal(w1_0, sdp["gcn.0.weight1"].numpy())
+    off = 4 * (7 * g + 0)   # 7*144 = 1008 is a multiple of 4: w1, w2, w1t, w2t of layer 0
+    w1_1 = packed[off: off + g * g].reshape(g, g)
+    w1t_1 = packed[off + 2 * g * g: off + 3 * g * g].reshape(g, g)
+    assert np.array_equal(w1_1, sdp["gcn.1.weight1"].numpy())
+    assert np.array_equal(w1t_1, sdp["gcn.1.weight1"].numpy().T)
+    # set encoder (PyTorch, once per call) equals the oracle's restatement
+    task = synthetic.synthetic_task(10, 20, seed=2)
+    with torch.no_grad():
+        assert torch.allclose(clf.set_encode(task)[0], O.set_encode(sdp, task), atol=1e-6)
+
+
+def test_schedule_table_matches_oracle_vpsde():
+    for beta_max, N in ((20.0, 1000), (5.0, 100)):
+        sde = sde_lib.VPSDE(0.1, beta_max, N)
+        osde = O.VPSDE(0.1, beta_max, N)
+        tab = sde.schedule_table(1e-3)
+        ts = O.timesteps(osde, 1e-3)
+        k = osde.timestep_index(ts)
+        assert tab.shape == (N, _lib.SCHED_COLS) and tab.dtype == np.float32
+        assert np.array_equal(tab[:, _lib.SCHED_T], ts.numpy())
+        assert np.array_equal(tab[:, _lib.SCHED_LABEL], (ts * 999).numpy())
+        assert np.array_equal(tab[:, _lib.SCHED_STD], osde.marginal_std(ts).numpy())
+        assert np.array_equal(tab[:, _lib.SCHED_ALPHA], osde.alphas[k].numpy())
+        _, G = osde.discretize(torch.zeros(N, 1, 1), ts)
+        assert np.array_equal(tab[:, _lib.SCHED_G], G.numpy())
+        assert np.array_equal(tab[:, _lib.SCHED_G2], (G ** 2).numpy())
+        assert int(k[0]) == N - 1 and int(k[-1]) == 0
+    assert sde_lib.VPSDE(0.1, 20, 1000).schedule_table(1e-3, 8).shape == (8, 8)
+    with pytest.raises(ValueError):
+        sde_lib.VPSDE(0.1, 20, 10).schedule_table(1e-3, 11)
+
+
+def test_registries_and_factory_errors_mirror_the_reference():
+    assert sampling.get_predictor("reverse_diffusion") is sampling.ReverseDiffusionPredictor
+    assert sampling.get_corrector("langevin") is sampling.LangevinCorrector
+    assert set(sampling._PREDICTORS) == {"euler_maruyama", "reverse_diffusion", "none"}
+    assert set(sampling._CORRECTORS) == {"langevin", "none"}
+    with pytest.raises(ValueError, match="Already registered"):
+        sampling.register_predictor(name="none")(object)
+    with pytest.raises(ValueError, match="Already registered model"):
+        mutils.register_model(name="CATE")(object)
+    assert mutils.get_model("CATE") is _cate.CATE and mutils.get_model("MetaNeuralPredictor") is _dm.MetaNeuralPredictor
+    cfg = score_config(CateDims(), "cpu")
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    inv = utils.get_data_inverse_scaler(cfg)
+    cfg.sampling["method"] = "ode"
+    with pytest.raises(NotImplementedError, match="Sampler name ode unknown"):
+        sampling.get_sampling_fn(cfg, sde, (4, 8, 7), inv, 1e-3)
+    cfg.sampling["method"] = "pc"
+    cfg.sampling["predictor"] = "euler_maruyama"
+    with pytest.raises(NotImplementedError):
+        sampling.get_sampling_fn(cfg, sde, (4, 8, 7), inv, 1e-3)
+    cfg.sampling["predictor"] = "reverse_diffusion"
+    with pytest.raises(NotImplementedError):
+        sampling.get_sampling_fn(cfg, sde_lib.VESDE(), (4, 8, 7), inv, 1e-3)
+    fn = sampling.get_sampling_fn(cfg, sde, (4, 8, 7), inv, 1e-3)
+    with pytest.raises(RuntimeError, match="MI355X only"):     # no CPU fallback
+        fn(mutils.create_model(cfg), utils.nb201_adj().unsqueeze(0))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mutils.create_model(cfg).eval()(torch.zeros(2, 8, 7), torch.zeros(2), torch.zeros(2, 8, 8))
+    with pytest.raises(NotImplementedError):
+        mutils.get_score_fn(sde, None, continuous=False)
+
+
+def test_mask_and_scaler_helpers():
+    adj = utils.nb201_adj()
+    assert torch.equal(adj, O.nb201_adj())
+    assert torch.equal(utils.aug_mask(adj, algo="floyd")[0], adj)          # the reference's typo path
+    assert torch.equal(utils.aug_mask(adj)[0], O.floyed(adj))
+    assert utils.aug_mask(adj.unsqueeze(0).repeat(3, 1, 1)).shape == (3, 8, 8)
+    cfg = score_config(CateDims(), "cpu")
+    x = torch.tensor([0.0, 0.25, 1.0])
+    assert torch.equal(utils.get_data_inverse_scaler(cfg)(utils.get_data_scaler(cfg)(x)), x)
+
+
+def test_shard_batch_partitions():
+    for total, world in ((65536, 8), (4096, 3), (5, 8), (7, 2)):
+        spans = [D.shard_batch(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and sum(c for _, c in spans) == total
+        for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+            assert s0 + c0 == s1
+        assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["DNAG_REPO"])
+from diffusionnag_amd import distributed as D
+rank, world, local = D.init_from_env("gloo")
+total = 7
+start, count = D.shard_batch(total, rank, world)
+x = (torch.arange(start, start + count, dtype=torch.float32)[:, None, None] + torch.zeros(count, 8, 7))
+full = D.gather_samples(x, total)
+assert full.shape == (total, 8, 7), full.shape
+assert torch.equal(full[:, 0, 0], torch.arange(total, dtype=torch.float32)), full[:, 0, 0]
+print("rank", rank, "ok")
+"""
+
+
+def test_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, DNAG_REPO=REPO, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
