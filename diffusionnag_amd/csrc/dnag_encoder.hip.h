@@ -64,22 +64,94 @@ __device__ __forceinline__ void zero_row(float (&b)[KH]) {
     for (int i = 0; i < KH; ++i) b[i] = 0.f;
 }
 
-// LayerNorm statistics of RP rows of width 64 (row stride HS): 16 lanes per row.
-template <int RP, int HS, int NT>
-__device__ __forceinline__ void ln_stats(const float *hbuf, float *mean, float *rstd) {
-    const int sub = threadIdx.x & 15, slot = threadIdx.x >> 4;
-    for (int r = slot; r < RP; r += NT / 16) {
-        const v4f v = *reinterpret_cast<const v4f *>(hbuf + r * HS + 4 * sub);
-        float s = (v.x + v.y) + (v.z + v.w);
-        s += __shfl_xor(s, 8, 16); s += __shfl_xor(s, 4, 16); s += __shfl_xor(s, 2, 16); s += __shfl_xor(s, 1, 16);
-        const float m = s * (1.0f / 64.0f);
-        const float dx = v.x - m, dy = v.y - m, dz = v.z - m, dw = v.w - m;
-        float q = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        q += __shfl_xor(q, 8, 16); q += __shfl_xor(q, 4, 16); q += __shfl_xor(q, 2, 16); q += __shfl_xor(q, 1, 16);
-        if (sub == 0) {
-            mean[r] = m;
-            rstd[r] = 1.0f / sqrtf(q * (1.0f / 64.0f) + 1e-5f);
+// ---------------------------------------------------------------------------------------------
+// DPP row reduction: total over the 16 lanes of a row, delivered to every lane of that row.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<0x140>(v);   // row_mirror
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tile jobs, second form: the B fragments of the wave's first tile are already in registers
+// (prefetched by the caller while the previous phase ran); a second tile, if the wave's job chunk
+// spans one, is loaded into b1 at entry.  LN = true normalises every A row on load:
+// (a - mean) * rstd with the statistics of the 64-wide row (this lane's 32 values + lane^32's),
+// i.e. LayerNorm without affine (gamma/beta are folded into W', b' at pack time).
+// ---------------------------------------------------------------------------------------------
+template <int NTILES, int MT, int NW>
+struct JobSplit {
+    static constexpr int njobs = NTILES * MT;
+    static constexpr int per = (njobs + NW - 1) / NW;
+    static constexpr int max_tiles() {
+        int m = 0;
+        for (int w = 0; w < NW; ++w) {
+            const int j0 = w * per, j1 = (j0 + per < njobs) ? j0 + per : njobs;
+            if (j0 < j1) { const int t = (j1 - 1) / MT - j0 / MT + 1; m = t > m ? t : m; }
         }
+        return m;
+    }
+    __device__ static __forceinline__ int first_tile(int wave) { return wave * per < njobs ? (wave * per) / MT : -1; }
+};
+
+template <int K, int NTILES, int MT, int NW, bool LN, typename BLoad, typename Epi>
+__device__ __forceinline__ void run_jobs2(const float *A, int as, float (&b0)[K / 2], float (&b1)[K / 2], BLoad bload, Epi epi) {
+    typedef JobSplit<NTILES, MT, NW> JS;
+    static_assert(JS::max_tiles() <= 2, "a wave's job chunk may span at most two column tiles");
+    static_assert(!LN || K == DNAG_D, "fused LayerNorm needs the whole row in one K pass");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int j0 = wave * JS::per;
+    const int j1 = (j0 + JS::per < JS::njobs) ? j0 + JS::per : JS::njobs;
+    if (j0 >= j1) return;
+    const int nt0 = j0 / MT;
+    if constexpr (JS::max_tiles() == 2) {
+        const int ntl = (j1 - 1) / MT;
+        if (ntl != nt0) bload(ntl, r, h, b1);
+    }
+    for (int j = j0; j < j1; ++j) {
+        const int nt = j / MT, mt = j - nt * MT;
+        constexpr int CH = (K / 2 > 32) ? 32 : K / 2;       // A is consumed in chunks of <= 32 floats per lane
+        const float *ap = A + (size_t)(mt * 32 + r) * as + h * (K / 2);
+        const bool first = (JS::max_tiles() == 1) || nt == nt0;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int c = 0; c < K / 2; c += CH) {
+            float a[CH];
+            load_row<CH>(ap + c, a);
+            if constexpr (LN) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) s += a[i];
+                s += __shfl_xor(s, 32);
+                const float m = s * (1.0f / K);
+                float q = 0.f;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) { a[i] -= m; q = fmaf(a[i], a[i], q); }
+                q += __shfl_xor(q, 32);
+                const float rs = 1.0f / sqrtf(q * (1.0f / K) + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) a[i] *= rs;
+            }
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) acc = mfma32(a[i], b0[c + i], acc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) acc = mfma32(a[i], b1[c + i], acc);
+            }
+        }
+        epi(mt, nt, r, h, acc);
     }
 }
 
@@ -92,7 +164,7 @@ struct EncGeom {
     static constexpr int HS = DNAG_D + 4;
     static constexpr int QW = (3 * DNAG_D > DFF) ? 3 * DNAG_D : DFF;
     static constexpr int QS = QW + 4;
-    static constexpr size_t lds_floats = (size_t)RP * HS + (size_t)RP * QS + 2 * RP + (size_t)G * N * N;
+    static constexpr size_t lds_floats = (size_t)RP * HS + (size_t)RP * QS + (size_t)G * N * N;
 };
 
 // x [batch][N][V]; temb [tstride ? batch : 1][64]; mask [mstride ? batch : 1][N][N];
@@ -101,20 +173,37 @@ template <int N, int V, int G, int H, int DFF, bool WITH_PE>
 __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict__ P, const CateLayout lay,
                                                          const float *__restrict__ x, const float *__restrict__ temb,
                                                          int tstride, const float *__restrict__ mask, int mstride,
-                                                         float *__restrict__ concat, float *__restrict__ attn0, int batch) {
+                                                         float *__restrict__ concat, float *__restrict__ attn0, int batch,
+                                                         int dbg_skip) {
     typedef EncGeom<N, G, DFF> Ge;
     constexpr int R = Ge::R, MT = Ge::MT, RP = Ge::RP, HS = Ge::HS, QS = Ge::QS;
     constexpr int D = DNAG_D, DK = D / H;
+    constexpr int NT_QKV = 3 * D / 32, NT_O = D / 32, NT_F1 = DFF / 32, NT_F2 = D / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hbuf = smem;                 // [RP][HS] residual stream
     float *qkv = hbuf + RP * HS;        // [RP][QS] q|k|v, then attention output in the q slot, then FFN hidden
-    float *mean = qkv + RP * QS;        // [RP]
-    float *rstd = mean + RP;            // [RP]
-    float *maskb = rstd + RP;           // [G][N][N]
+    float *maskb = qkv + RP * QS;       // [G][N][N]
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
+
+    // weight tiles kept in registers across phases: bP/bQ (K = 64) and bR (K = DFF)
+    float bP[D / 2], bQ[D / 2], bR[DFF / 2];
+    // The weights are const __restrict__, so the compiler may hoist these loads above barriers and then
+    // spill them; passing the address through an opaque asm pins the issue point of every prefetch.
+    auto load_w64 = [&](const float *W, int nt, float (&b)[D / 2]) {
+        const float *w = W + (size_t)(nt * 32 + fr) * D + fh * (D / 2);
+        asm volatile("" : "+v"(w));
+        load_row<D / 2>(w, b);
+    };
+    const int ft_qkv = JobSplit<NT_QKV, MT, 4>::first_tile(wave);
+    const int ft_o = JobSplit<NT_O, MT, 4>::first_tile(wave);
+    const int ft_f1 = JobSplit<NT_F1, MT, 4>::first_tile(wave);
+    const int ft_f2 = JobSplit<NT_F2, MT, 4>::first_tile(wave);
+    if (ft_qkv >= 0) load_w64(P + lay.layer0 + lay.l_wqkv, ft_qkv, bP);
 
     // ---- stage inputs -------------------------------------------------------------------------
     float *xin = qkv;                   // [R][V] alias
@@ -149,25 +238,14 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         }
     }
     __syncthreads();
-    ln_stats<RP, HS, 256>(hbuf, mean, rstd);
-    __syncthreads();
-
-    auto ln_xf = [&](v4f a, int row) {
-        const float m = mean[row], s = rstd[row];
-        a.x = (a.x - m) * s; a.y = (a.y - m) * s; a.z = (a.z - m) * s; a.w = (a.w - m) * s;
-        return a;
-    };
-    auto id_xf = [](v4f a, int) { return a; };
 
     for (int l = 0; l < L; ++l) {
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
         // ---- QKV = LN1(h) Wqkv'^T + bqkv' --------------------------------------------------------
-        {
+        if (!(dbg_skip & 1)) {
             const float *W = LP + lay.l_wqkv, *bias = LP + lay.l_bqkv;
-            run_jobs<D, MT, 4>(
-                3 * D / 32, hbuf, HS,
-                [&](int nt, int r, int h, float (&b)[D / 2]) { load_row<D / 2>(W + (size_t)(nt * 32 + r) * D + h * (D / 2), b); },
-                ln_xf,
+            run_jobs2<D, NT_QKV, MT, 4, true>(
+                hbuf, HS, bP, bQ, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
                     const float bv = bias[col];
@@ -175,20 +253,16 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     for (int i = 0; i < 16; ++i) qkv[(mt * 32 + acc_row(i, h)) * QS + col] = acc[i] + bv;
                 });
         }
+        constexpr bool PF_ATT = N <= 8;   // larger graphs need the registers for the attention rows
+        if (PF_ATT && ft_o >= 0) load_w64(LP + lay.l_wo, ft_o, bP);   // lands while attention runs
         __syncthreads();
         // ---- attention per (graph, head, query) ---------------------------------------------------
+        if (!(dbg_skip & 2))
         for (int it = tid; it < G * H * N; it += 256) {
             const int i = it % N, hd = (it / N) % H, g = it / (N * H);
             const int row = g * N + i;
             float q[DK];
-            {
-                const float *qp = qkv + row * QS + hd * DK;
-#pragma unroll
-                for (int e = 0; e < DK; e += 4) {
-                    const v4f v4 = *reinterpret_cast<const v4f *>(qp + e);
-                    q[e] = v4.x; q[e + 1] = v4.y; q[e + 2] = v4.z; q[e + 3] = v4.w;
-                }
-            }
+            load_row<DK>(qkv + row * QS + hd * DK, q);
             float s[N];
             float mx = -3.0e38f;
 #pragma unroll
@@ -229,14 +303,13 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
 #pragma unroll
             for (int e = 0; e < DK; e += 4) *reinterpret_cast<v4f *>(op + e) = v4f{o[e], o[e + 1], o[e + 2], o[e + 3]};
         }
+        if (!PF_ATT && ft_o >= 0) load_w64(LP + lay.l_wo, ft_o, bP);
         __syncthreads();
         // ---- h += attn Wo^T + bo ------------------------------------------------------------------
-        {
+        if (!(dbg_skip & 4)) {
             const float *W = LP + lay.l_wo, *bias = LP + lay.l_bo;
-            run_jobs<D, MT, 4>(
-                D / 32, qkv, QS,
-                [&](int nt, int r, int h, float (&b)[D / 2]) { load_row<D / 2>(W + (size_t)(nt * 32 + r) * D + h * (D / 2), b); },
-                id_xf,
+            run_jobs2<D, NT_O, MT, 4, false>(
+                qkv, QS, bP, bP, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
                     const float bv = bias[col];
@@ -247,16 +320,18 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     }
                 });
         }
-        __syncthreads();
-        ln_stats<RP, HS, 256>(hbuf, mean, rstd);
+        if (ft_f1 >= 0) load_w64(LP + lay.l_w1, ft_f1, bQ);
+        if (ft_f2 >= 0) {
+            const float *w = LP + lay.l_w2 + (size_t)(ft_f2 * 32 + fr) * DFF + fh * (DFF / 2);
+            asm volatile("" : "+v"(w));
+            load_row<DFF / 2>(w, bR);
+        }
         __syncthreads();
         // ---- hidden = relu(LN2(h) W1'^T + b1') -----------------------------------------------------
-        {
+        if (!(dbg_skip & 8)) {
             const float *W = LP + lay.l_w1, *bias = LP + lay.l_b1;
-            run_jobs<D, MT, 4>(
-                DFF / 32, hbuf, HS,
-                [&](int nt, int r, int h, float (&b)[D / 2]) { load_row<D / 2>(W + (size_t)(nt * 32 + r) * D + h * (D / 2), b); },
-                ln_xf,
+            run_jobs2<D, NT_F1, MT, 4, true>(
+                hbuf, HS, bQ, bP, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
                     const float bv = bias[col];
@@ -264,14 +339,14 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     for (int i = 0; i < 16; ++i) qkv[(mt * 32 + acc_row(i, h)) * QS + col] = fmaxf(acc[i] + bv, 0.f);
                 });
         }
+        if (l + 1 < L && ft_qkv >= 0) load_w64(LP + lay.layer_stride + lay.l_wqkv, ft_qkv, bP);   // next layer's first tile
         __syncthreads();
         // ---- h += hidden W2^T + b2 ----------------------------------------------------------------
-        {
+        if (!(dbg_skip & 16)) {
             const float *W = LP + lay.l_w2, *bias = LP + lay.l_b2;
-            run_jobs<DFF, MT, 4>(
-                D / 32, qkv, QS,
+            run_jobs2<DFF, NT_F2, MT, 4, false>(
+                qkv, QS, bR, bR,
                 [&](int nt, int r, int h, float (&b)[DFF / 2]) { load_row<DFF / 2>(W + (size_t)(nt * 32 + r) * DFF + h * (DFF / 2), b); },
-                id_xf,
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
                     const float bv = bias[col];
@@ -283,25 +358,29 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                 });
         }
         __syncthreads();
-        // ---- layer output norm (transformer.py:177) -> concat slice; same stats feed the next LN1 --
-        ln_stats<RP, HS, 256>(hbuf, mean, rstd);
-        __syncthreads();
-        {
+        // ---- layer output norm (transformer.py:177) -> concat slice: 16 lanes per row, DPP statistics ----
+        if (!(dbg_skip & 64)) {
             const float *og = LP + lay.l_ong, *ob = LP + lay.l_onb;
             const int sub = tid & 15, slot = tid >> 4;
             const v4f g4 = *reinterpret_cast<const v4f *>(og + 4 * sub);
             const v4f b4 = *reinterpret_cast<const v4f *>(ob + 4 * sub);
-            for (int r = slot; r < R; r += 16) {
+#pragma unroll
+            for (int p = 0; p < RP / 16; ++p) {
+                const int r = slot + 16 * p;
+                v4f v = *reinterpret_cast<const v4f *>(hbuf + r * HS + 4 * sub);
+                const float m = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
+                v.x -= m; v.y -= m; v.z -= m; v.w -= m;
+                const float var = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 64.0f);
+                const float s = 1.0f / sqrtf(var + 1e-5f);
                 const int g = r / N;
-                if (g0 + g >= batch) continue;
-                const v4f v = *reinterpret_cast<const v4f *>(hbuf + r * HS + 4 * sub);
-                const float m = mean[r], s = rstd[r];
-                v4f o4;
-                o4.x = (v.x - m) * s * g4.x + b4.x; o4.y = (v.y - m) * s * g4.y + b4.y;
-                o4.z = (v.z - m) * s * g4.z + b4.z; o4.w = (v.w - m) * s * g4.w + b4.w;
-                *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + r) * lay.F + l * D + 4 * sub) = o4;
+                if (r < R && g0 + g < batch) {
+                    v4f o4;
+                    o4.x = v.x * s * g4.x + b4.x; o4.y = v.y * s * g4.y + b4.y;
+                    o4.z = v.z * s * g4.z + b4.z; o4.w = v.w * s * g4.w + b4.w;
+                    *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + r) * lay.F + l * D + 4 * sub) = o4;
+                }
             }
         }
-        // no barrier needed: the next phase only reads hbuf/mean/rstd and writes qkv
+        // no barrier needed: the next phase only reads hbuf and writes qkv
     }
 }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -271,6 +272,9 @@ extern "C" int dnag_timing_end(void) {
     return 0;
 }
 
+// debug only: DNAG_ENC_SKIP / DNAG_PRED_SKIP are phase bit masks for timing ablations (outputs become wrong)
+static int env_int(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+
 // ---------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------
@@ -320,7 +324,7 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
         attr_set = true;
     }
     const int grid = (batch + G - 1) / G;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch, env_int("DNAG_ENC_SKIP"));
     LAUNCH_CHECK();
     return 0;
 }
@@ -354,7 +358,7 @@ static int launch_predictor(const PredLayout &lay, const float *P, const float *
         attr_lds = lds;
     }
     const int grid = (batch + 3) / 4;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, d_mu, y, grad, batch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, d_mu, y, grad, batch, env_int("DNAG_PRED_SKIP"));
     LAUNCH_CHECK();
     return 0;
 }

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
                                                                     const float *__restrict__ x, const float *__restrict__ temb,
                                                                     int tstride, const float *__restrict__ mask, int mstride,
                                                                     const float *__restrict__ d_mu, float *__restrict__ y,
-                                                                    float *__restrict__ grad, int batch) {
+                                                                    float *__restrict__ grad, int batch, int dbg_skip) {
     typedef PredGeom<N, V, G> Ge;
     constexpr int R = Ge::R, HS = PRED_HS, GH = PRED_GH, NT = PRED_NW * 64, LH = 128;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
     __syncthreads();   // Ah (aliasing U1) is dead from here
 
     // ---- layer 0: K = V, plain FMAs -----------------------------------------------------------
-    {
+    if (!(dbg_skip & 1)) {
         // U[r][v] = sum_r' A[r][r'] x[r'][v] -> kept in registers per (r, c) item below
         const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]
         for (int i = tid; i < R * GH; i += NT) {
@@ -166,12 +166,13 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
 
     // ---- layers 1 .. L-1 forward -----------------------------------------------------------------
     for (int l = 1; l < L; ++l) {
-        mix_fwd();
+        if (!(dbg_skip & 2)) mix_fwd();
         __syncthreads();
         const float *W1t = P + lay.w1t[l], *W2t = P + lay.w2t[l];   // [GH out][GH in]
         uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
         f32x16 acc1;
         // each wave owns one column tile; Z1 and Z2 computed back to back with the same registers
+        if (!(dbg_skip & 4)) {
         run_jobs<GH, 1, PRED_NW>(
             PRED_NT, U1, HS,
             [&](int nt, int r, int h, float (&b)[GH / 2]) {
@@ -199,10 +200,12 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
                     if (col < GH) Hb[row * HS + col] = (fmaxf(acc1[i], 0.f) + fmaxf(acc2[i], 0.f)) / 2.f;
                 }
             });
+        }
         __syncthreads();
     }
 
     // ---- head forward -----------------------------------------------------------------------------
+    if (!(dbg_skip & 8)) {
     for (int i = tid; i < G * GH; i += NT) {
         const int g = i / GH, c = i - g * GH;
         float s = 0.f;
@@ -227,6 +230,7 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
         for (int o = 0; o < LH; ++o) acc = fmaf(w[(size_t)o * hs], avec[g * LH + o], acc);
         tv[g * TS + j] = tanhf(acc + c0[j]);
     }
+    }
     __syncthreads();
     if (y != nullptr && tid < G && g0 + tid < batch) {
         float acc = 0.f;
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
     __syncthreads();
 
     // ---- head backward ----------------------------------------------------------------------------
+    if (!(dbg_skip & 16)) {
     for (int i = tid; i < G * hs; i += NT) {   // dpre = w2 (1 - tanh^2)
         const int g = i / hs, j = i - g * hs;
         const float t = tv[g * TS + j];
@@ -262,6 +267,7 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
     for (int i = tid; i < R * GH; i += NT) {
         const int r = i / GH, c = i - r * GH;
         Hb[r * HS + c] = pbar[(r / N) * GH + c];
+    }
     }
     __syncthreads();
 
@@ -289,10 +295,11 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
 
     // ---- layers L-1 .. 1 backward: dH_l = P1 W1^T + P2 W2^T  (B rows = W[in][:] K-contiguous) ------
     for (int l = L - 1; l >= 1; --l) {
-        mix_bwd(l);
+        if (!(dbg_skip & 32)) mix_bwd(l);
         __syncthreads();
         const float *W1 = P + lay.w1[l], *W2 = P + lay.w2[l];   // [GH in][GH out]
         f32x16 acc1;
+        if (!(dbg_skip & 64)) {
         run_jobs<GH, 1, PRED_NW>(
             PRED_NT, U1, HS,
             [&](int nt, int r, int h, float (&b)[GH / 2]) {
@@ -314,12 +321,13 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
                     for (int i = 0; i < 16; ++i) Hb[acc_row(i, h) * HS + col] = acc1[i] + acc2[i];
                 }
             });
+        }
         __syncthreads();
     }
     // ---- layer 0 backward: dx[r][v] = sum_c P1[r][c] W1[v][c] + P2[r][c] W2[v][c] -------------------
-    mix_bwd(0);
+    if (!(dbg_skip & 32)) mix_bwd(0);
     __syncthreads();
-    {
+    if (!(dbg_skip & 128)) {
         const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]
         for (int i = tid; i < R * V; i += NT) {
             const int r = i / V, v = i - r * V;
