@@ -349,15 +349,15 @@ static int launch_exit(const dnag_cate_dims &c, const CateLayout &lay, const flo
 
 static int launch_predictor(const PredLayout &lay, const float *P, const float *x, const float *temb, int tstride,
                             const float *mask, int mstride, const float *d_mu, float *y, float *grad, int batch, hipStream_t st) {
-    typedef PredGeom<8, 7, 4> Ge;
+    typedef PredGeom<8, 7> Ge;
     const size_t lds = Ge::lds_bytes(lay.hs, lay.L);
-    auto kern = predictor_kernel<8, 7, 4>;
+    auto kern = predictor_kernel<8, 7>;
     static size_t attr_lds = 0;
     if (lds > attr_lds) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_lds = lds;
     }
-    const int grid = (batch + 3) / 4;
+    const int grid = (batch + Ge::G - 1) / Ge::G;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, d_mu, y, grad, batch, env_int("DNAG_PRED_SKIP"));
     LAUNCH_CHECK();
     return 0;

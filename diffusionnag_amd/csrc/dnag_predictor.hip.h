@@ -1,5 +1,5 @@
-// MetaNeuralPredictor surrogate: forward and analytic input gradient, one workgroup per G graphs,
-// all activations in LDS.  Included by dnag_lib.hip.
+// MetaNeuralPredictor surrogate: forward and analytic input gradient, one workgroup per G = 8 graphs
+// (64 rows), 10 waves, all activations in LDS.  Included by dnag_lib.hip.
 //
 // Restates (reference NAS-Bench-201/): models/digcn_meta.py:109-129 (arch_encode), :39-48
 // (DirectedGraphConvolution), :12-22 (normalize_adj, graph_pooling), :141-159 (predict/forward) and
@@ -10,6 +10,10 @@
 //   p = sum_n H_L[n] / N + tau ;  a = Wfc1 p ;  y = w2 . tanh(W0 [D_mu | a] + b0) + b2
 // Backward (dy/dx only): dpre = w2 (1 - tanh^2); da = W0[:, nz:]^T dpre; dp = Wfc1^T da;
 //   dH_L[n] = dp / N;  per layer  dH_l = (A1^T (1/2 dH_{l+1} . [Z1>0])) W1^T + (A2^T (...[Z2>0])) W2^T.
+//
+// Every product with K >= 128 runs on v_mfma_f32_32x32x2_f32 (column tiles of 32: 144 = 4.5 tiles,
+// one (column tile, row tile) job per wave); the 8x8 adjacency mixing, the K = 7 first layer and the
+// hs-wide tanh head are plain FMAs.
 #pragma once
 #include "dnag_common.h"
 #include "dnag_encoder.hip.h"
@@ -17,24 +21,24 @@
 #define PRED_GH 144        // gcn_hidden (configs/tr_meta_surrogate.py:97)
 #define PRED_HS 148        // LDS row stride of [R][144] buffers (148 % 64 == 20: conflict-free b128 reads)
 #define PRED_NT 5          // ceil(144 / 32) column tiles
-#define PRED_NW 5          // waves per workgroup: one column tile each
+#define PRED_G 8           // graphs per workgroup
+#define PRED_NW 10         // waves per workgroup: one (column tile, row tile) job each
 #define PRED_MAXHS 512
 
-template <int N, int V, int G>
+template <int N, int V>
 struct PredGeom {
+    static constexpr int G = PRED_G;
     static constexpr int R = G * N;
-    static_assert(R == 32, "one 32-row MFMA tile per workgroup");
-    static constexpr int XF = (R * V + 11) / 4 * 4;                   // staged x, padded
+    static constexpr int MT = R / 32;
+    static_assert(R % 32 == 0 && PRED_NT * MT == PRED_NW, "one MFMA job per wave");
+    static constexpr int XS = 8;                                      // row stride of the staged x / A x buffers
     // dynamic LDS bytes for `hs` head units and `L` DiGCN layers
     static size_t lds_bytes(int hs, int L) {
         const size_t hs4 = align4((size_t)hs);
         const size_t fl = 3 * (size_t)R * PRED_HS      // H, U1, U2
                           + 2 * (size_t)G * N * N      // A1, A2
-                          + (size_t)G * PRED_GH        // pbar / dp
-                          + (size_t)G * 128            // a / da
-                          + (size_t)G * hs4            // tanh / dpre
-                          + hs4                        // c0
-                          + XF                         // x
+                          + (size_t)(G + 1) * hs4      // tanh / dpre, c0
+                          + 3 * (size_t)R * XS         // x, A1 x, A2 x
                           + (size_t)L * 2 * R * PRED_NT;   // relu bit masks (uint32)
         return fl * sizeof(float);
     }
@@ -42,37 +46,39 @@ struct PredGeom {
 
 // x [batch][N][V]; temb [tstride ? batch : 1][144]; mask [mstride ? batch : 1][N][N]; d_mu [nz];
 // y [batch] or null; grad [batch][N][V] or null.
-template <int N, int V, int G>
-__global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float *__restrict__ P, const PredLayout lay,
-                                                                    const float *__restrict__ x, const float *__restrict__ temb,
-                                                                    int tstride, const float *__restrict__ mask, int mstride,
-                                                                    const float *__restrict__ d_mu, float *__restrict__ y,
-                                                                    float *__restrict__ grad, int batch, int dbg_skip) {
-    typedef PredGeom<N, V, G> Ge;
-    constexpr int R = Ge::R, HS = PRED_HS, GH = PRED_GH, NT = PRED_NW * 64, LH = 128;
+template <int N, int V>
+__global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__restrict__ P, const PredLayout lay,
+                                                                 const float *__restrict__ x, const float *__restrict__ temb,
+                                                                 int tstride, const float *__restrict__ mask, int mstride,
+                                                                 const float *__restrict__ d_mu, float *__restrict__ y,
+                                                                 float *__restrict__ grad, int batch, int dbg_skip) {
+    typedef PredGeom<N, V> Ge;
+    static_assert(N == 8, "adjacency mixing is written for 8-node graphs");
+    constexpr int G = Ge::G, R = Ge::R, MT = Ge::MT, HS = PRED_HS, GH = PRED_GH, NT = PRED_NW * 64, LH = 128, XS = Ge::XS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *Hb = smem;                       // [R][HS]
     float *U1 = Hb + R * HS;                // [R][HS]
     float *U2 = U1 + R * HS;                // [R][HS]
     float *A1 = U2 + R * HS;                // [G][N][N]
     float *A2 = A1 + G * N * N;             // [G][N][N]
-    float *pbar = A2 + G * N * N;           // [G][GH]
-    float *avec = pbar + G * GH;            // [G][LH]
     const int L = lay.L, hs = lay.hs, nz = lay.nz;
     const int TS = (hs + 3) & ~3;           // row stride of tv
-    float *tv = avec + G * LH;              // [G][TS]
+    float *tv = A2 + G * N * N;             // [G][TS]
     float *c0 = tv + G * TS;                // [TS]
-    float *xin = c0 + TS;                   // [R][V]
-    uint32_t *bits = reinterpret_cast<uint32_t *>(xin + Ge::XF);   // [L][2][R][NT] (cols of tile nt, row r)
+    float *xin = c0 + TS;                   // [R][XS]
+    float *ux1 = xin + R * XS;              // [R][XS] A1 x
+    float *ux2 = ux1 + R * XS;              // [R][XS] A2 x
+    uint32_t *bits = reinterpret_cast<uint32_t *>(ux2 + R * XS);   // [L][2][R][NT] (cols of tile nt, row r)
     float *Ah = U1;                         // scratch for Ahat during set-up
 
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * G;
 
     // ---- inputs ---------------------------------------------------------------------------------
-    for (int i = tid; i < R * V; i += NT) {
-        const int g = i / (N * V);
-        xin[i] = (g0 + g < batch) ? x[(size_t)g0 * N * V + i] : 0.f;
+    for (int i = tid; i < R * XS; i += NT) {
+        const int r = i / XS, v = i - r * XS;
+        const int g = r / N;
+        xin[i] = (v < V && g0 + g < batch) ? x[((size_t)g0 * N + r) * V + v] : 0.f;
     }
     // Ahat = rn(M + I)   (digcn_meta.py:120)
     for (int i = tid; i < G * N; i += NT) {
@@ -107,61 +113,100 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
     }
     __syncthreads();   // Ah (aliasing U1) is dead from here
 
-    // ---- layer 0: K = V, plain FMAs -----------------------------------------------------------
+    // ---- layer 0 (K = V): A1 x and A2 x once, then Z = (A x) W on FMAs -----------------------------
     if (!(dbg_skip & 1)) {
-        // U[r][v] = sum_r' A[r][r'] x[r'][v] -> kept in registers per (r, c) item below
+        for (int i = tid; i < R * XS; i += NT) {
+            const int r = i / XS, v = i - r * XS;
+            const int g = r / N, n = r - g * N;
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float xv = xin[(g * N + j) * XS + v];
+                u1 = fmaf(A1[(g * N + n) * N + j], xv, u1);
+                u2 = fmaf(A2[(g * N + n) * N + j], xv, u2);
+            }
+            ux1[i] = u1;
+            ux2[i] = u2;
+        }
+        __syncthreads();
         const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]
         for (int i = tid; i < R * GH; i += NT) {
             const int r = i / GH, c = i - r * GH;
-            const int g = r / N, n = r - g * N;
             float z1 = 0.f, z2 = 0.f;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
-                float u1 = 0.f, u2 = 0.f;
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const float xv = xin[(g * N + j) * V + v];
-                    u1 = fmaf(A1[(g * N + n) * N + j], xv, u1);
-                    u2 = fmaf(A2[(g * N + n) * N + j], xv, u2);
-                }
-                z1 = fmaf(u1, W1[v * GH + c], z1);
-                z2 = fmaf(u2, W2[v * GH + c], z2);
+                z1 = fmaf(ux1[r * XS + v], W1[v * GH + c], z1);
+                z2 = fmaf(ux2[r * XS + v], W2[v * GH + c], z2);
             }
             Hb[r * HS + c] = (fmaxf(z1, 0.f) + fmaxf(z2, 0.f)) / 2.f;
-            // relu masks of layer 0 as bytes packed later: store sign bits in U1/U2 scratch
-            U1[r * HS + c] = z1 > 0.f ? 1.f : 0.f;
+            U1[r * HS + c] = z1 > 0.f ? 1.f : 0.f;   // relu masks, packed into bit words below
             U2[r * HS + c] = z2 > 0.f ? 1.f : 0.f;
         }
         __syncthreads();
-        // pack layer-0 masks into bit words: word (which, r, nt) covers cols nt*32 .. nt*32+31
         for (int i = tid; i < 2 * R * PRED_NT; i += NT) {
             const int nt = i % PRED_NT, r = (i / PRED_NT) % R, which = i / (PRED_NT * R);
-            const float *src = which ? U2 : U1;
+            const float *src = (which ? U2 : U1) + r * HS + nt * 32;
             uint32_t w = 0;
-            for (int b = 0; b < 32; ++b) {
-                const int c = nt * 32 + b;
-                if (c < GH && src[r * HS + c] != 0.f) w |= (1u << b);
-            }
-            bits[(size_t)(0 * 2 + which) * R * PRED_NT + r * PRED_NT + nt] = w;
+            const int nb = (GH - nt * 32 < 32) ? GH - nt * 32 : 32;
+            for (int b = 0; b < nb; ++b)
+                if (src[b] != 0.f) w |= (1u << b);
+            bits[(size_t)which * R * PRED_NT + r * PRED_NT + nt] = w;
         }
         __syncthreads();
     }
 
     auto id_xf = [](v4f a, int) { return a; };
-    auto mix_fwd = [&]() {   // U1 = A1 H, U2 = A2 H  (per graph)
-        for (int i = tid; i < R * GH; i += NT) {
-            const int r = i / GH, c = i - r * GH;
-            const int g = r / N, n = r - g * N;
-            float u1 = 0.f, u2 = 0.f;
+    // adjacency mixing, one (graph, column) item per thread: the 8 rows of the column stay in registers
+    auto mix_fwd = [&]() {   // U1 = A1 H, U2 = A2 H
+        for (int i = tid; i < G * GH; i += NT) {
+            const int g = i / GH, c = i - g * GH;
+            float hv[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) hv[j] = Hb[(g * N + j) * HS + c];
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                float a1[N], a2[N];
+                load_row<N>(A1 + (g * N + n) * N, a1);
+                load_row<N>(A2 + (g * N + n) * N, a2);
+                float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < N; ++j) { u1 = fmaf(a1[j], hv[j], u1); u2 = fmaf(a2[j], hv[j], u2); }
+                U1[(g * N + n) * HS + c] = u1;
+                U2[(g * N + n) * HS + c] = u2;
+            }
+        }
+    };
+    // P1 = A1^T (1/2 dH . m1), P2 = A2^T (1/2 dH . m2) into U1, U2
+    auto mix_bwd = [&](int l) {
+        const uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
+        for (int i = tid; i < G * GH; i += NT) {
+            const int g = i / GH, c = i - g * GH;
+            const int nt = c >> 5, bit = c & 31;
+            float p1[N], p2[N];
+#pragma unroll
+            for (int n = 0; n < N; ++n) { p1[n] = 0.f; p2[n] = 0.f; }
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                const float hv = Hb[(g * N + j) * HS + c];
-                u1 = fmaf(A1[(g * N + n) * N + j], hv, u1);
-                u2 = fmaf(A2[(g * N + n) * N + j], hv, u2);
+                const int rj = g * N + j;
+                const float dh = Hb[rj * HS + c] * 0.5f;
+                const float d1 = ((bl[(0 * R + rj) * PRED_NT + nt] >> bit) & 1u) ? dh : 0.f;
+                const float d2 = ((bl[(1 * R + rj) * PRED_NT + nt] >> bit) & 1u) ? dh : 0.f;
+                float a1[N], a2[N];
+                load_row<N>(A1 + rj * N, a1);
+                load_row<N>(A2 + rj * N, a2);
+#pragma unroll
+                for (int n = 0; n < N; ++n) { p1[n] = fmaf(a1[n], d1, p1[n]); p2[n] = fmaf(a2[n], d2, p2[n]); }
             }
-            U1[r * HS + c] = u1;
-            U2[r * HS + c] = u2;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                U1[(g * N + n) * HS + c] = p1[n];
+                U2[(g * N + n) * HS + c] = p2[n];
+            }
         }
+    };
+    auto load_b144 = [&](const float *W, int nt, int r, int h, float (&b)[GH / 2]) {   // rows of W are K-contiguous
+        const int col = nt * 32 + r;
+        if (col < GH) load_row<GH / 2>(W + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
     };
 
     // ---- layers 1 .. L-1 forward -----------------------------------------------------------------
@@ -170,66 +215,63 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
         __syncthreads();
         const float *W1t = P + lay.w1t[l], *W2t = P + lay.w2t[l];   // [GH out][GH in]
         uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
-        f32x16 acc1;
-        // each wave owns one column tile; Z1 and Z2 computed back to back with the same registers
         if (!(dbg_skip & 4)) {
-        run_jobs<GH, 1, PRED_NW>(
-            PRED_NT, U1, HS,
-            [&](int nt, int r, int h, float (&b)[GH / 2]) {
-                const int col = nt * 32 + r;
-                if (col < GH) load_row<GH / 2>(W1t + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
-            },
-            id_xf, [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
-        run_jobs<GH, 1, PRED_NW>(
-            PRED_NT, U2, HS,
-            [&](int nt, int r, int h, float (&b)[GH / 2]) {
-                const int col = nt * 32 + r;
-                if (col < GH) load_row<GH / 2>(W2t + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
-            },
-            id_xf,
-            [&](int, int nt, int r, int h, const f32x16 &acc2) {
-                const int col = nt * 32 + r;
+            f32x16 acc1;
+            // each wave owns one (column tile, row tile); Z1 and Z2 back to back with the same registers
+            run_jobs<GH, MT, PRED_NW>(
+                PRED_NT, U1, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W1t, nt, r, h, b); }, id_xf,
+                [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
+            run_jobs<GH, MT, PRED_NW>(
+                PRED_NT, U2, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W2t, nt, r, h, b); }, id_xf,
+                [&](int mt, int nt, int r, int h, const f32x16 &acc2) {
+                    const int col = nt * 32 + r;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int row = acc_row(i, h);
-                    const unsigned long long m1 = __ballot(acc1[i] > 0.f), m2 = __ballot(acc2[i] > 0.f);
-                    if (r == 0) {   // lanes 0 and 32: one word per (row, tile) and mask
-                        bl[(0 * R + row) * PRED_NT + nt] = (uint32_t)(h ? (m1 >> 32) : m1);
-                        bl[(1 * R + row) * PRED_NT + nt] = (uint32_t)(h ? (m2 >> 32) : m2);
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = mt * 32 + acc_row(i, h);
+                        const unsigned long long m1 = __ballot(acc1[i] > 0.f), m2 = __ballot(acc2[i] > 0.f);
+                        if (r == 0) {   // lanes 0 and 32: one word per (row, tile) and mask
+                            bl[(0 * R + row) * PRED_NT + nt] = (uint32_t)(h ? (m1 >> 32) : m1);
+                            bl[(1 * R + row) * PRED_NT + nt] = (uint32_t)(h ? (m2 >> 32) : m2);
+                        }
+                        if (col < GH) Hb[row * HS + col] = (fmaxf(acc1[i], 0.f) + fmaxf(acc2[i], 0.f)) / 2.f;
                     }
-                    if (col < GH) Hb[row * HS + col] = (fmaxf(acc1[i], 0.f) + fmaxf(acc2[i], 0.f)) / 2.f;
-                }
-            });
+                });
         }
         __syncthreads();
     }
 
-    // ---- head forward -----------------------------------------------------------------------------
+    // ---- head forward: graphs become the rows 0..G-1 of a 32-row MFMA tile ---------------------------
     if (!(dbg_skip & 8)) {
-    for (int i = tid; i < G * GH; i += NT) {
-        const int g = i / GH, c = i - g * GH;
-        float s = 0.f;
+        for (int i = tid; i < G * GH; i += NT) {
+            const int g = i / GH, c = i - g * GH;
+            float s = 0.f;
 #pragma unroll
-        for (int n = 0; n < N; ++n) s += Hb[(g * N + n) * HS + c];
-        const int gg = (g0 + g < batch) ? g0 + g : 0;
-        pbar[i] = s / (float)N + temb[(size_t)(tstride ? gg : 0) * GH + c];   // digcn_meta.py:19-22, :125
-    }
-    __syncthreads();
-    for (int i = tid; i < G * LH; i += NT) {   // a = Wfc1 p  (fc1t [GH][LH])
-        const int g = i / LH, o = i - g * LH;
-        const float *w = P + lay.fc1t + o;
-        float acc = 0.f;
-        for (int c = 0; c < GH; ++c) acc = fmaf(w[(size_t)c * LH], pbar[g * GH + c], acc);
-        avec[i] = acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < G * hs; i += NT) {   // tanh(W0a a + c0)  (p0_at [LH][hs])
-        const int g = i / hs, j = i - g * hs;
-        const float *w = P + lay.p0_at + j;
-        float acc = 0.f;
-        for (int o = 0; o < LH; ++o) acc = fmaf(w[(size_t)o * hs], avec[g * LH + o], acc);
-        tv[g * TS + j] = tanhf(acc + c0[j]);
-    }
+            for (int n = 0; n < N; ++n) s += Hb[(g * N + n) * HS + c];
+            const int gg = (g0 + g < batch) ? g0 + g : 0;
+            U1[g * HS + c] = s / (float)N + temb[(size_t)(tstride ? gg : 0) * GH + c];   // digcn_meta.py:19-22, :125
+        }
+        __syncthreads();
+        // a = Wfc1 p  (fc1 [LH][GH]: rows K-contiguous) -> U2[g][0..127]
+        run_jobs<GH, 1, PRED_NW>(
+            LH / 32, U1, HS,
+            [&](int nt, int r, int h, float (&b)[GH / 2]) { load_row<GH / 2>(P + lay.fc1 + (size_t)(nt * 32 + r) * GH + h * (GH / 2), b); },
+            id_xf,
+            [&](int, int nt, int r, int h, const f32x16 &acc) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int row = acc_row(i, h);
+                    if (row < G) U2[row * HS + nt * 32 + r] = acc[i];
+                }
+            });
+        __syncthreads();
+        for (int i = tid; i < G * hs; i += NT) {   // tanh(W0a a + c0)  (p0_at [LH][hs])
+            const int g = i / hs, j = i - g * hs;
+            const float *w = P + lay.p0_at + j;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int o = 0; o < LH; ++o) acc = fmaf(w[(size_t)o * hs], U2[g * HS + o], acc);
+            tv[g * TS + j] = tanhf(acc + c0[j]);
+        }
     }
     __syncthreads();
     if (y != nullptr && tid < G && g0 + tid < batch) {
@@ -242,102 +284,88 @@ __global__ __launch_bounds__(PRED_NW * 64, 2) void predictor_kernel(const float 
 
     // ---- head backward ----------------------------------------------------------------------------
     if (!(dbg_skip & 16)) {
-    for (int i = tid; i < G * hs; i += NT) {   // dpre = w2 (1 - tanh^2)
-        const int g = i / hs, j = i - g * hs;
-        const float t = tv[g * TS + j];
-        tv[g * TS + j] = P[lay.p2_w + j] * (1.f - t * t);
-    }
-    __syncthreads();
-    for (int i = tid; i < G * LH; i += NT) {   // da[o] = sum_j W0[j][nz + o] dpre[j]
-        const int g = i / LH, o = i - g * LH;
-        const float *w = P + lay.p0_w + nz + o;
-        float acc = 0.f;
-        for (int j = 0; j < hs; ++j) acc = fmaf(w[(size_t)j * (nz + LH)], tv[g * TS + j], acc);
-        avec[i] = acc;
-    }
-    __syncthreads();
-    for (int i = tid; i < G * GH; i += NT) {   // dp[c] = sum_o Wfc1[o][c] da[o];  dH_L[n][c] = dp[c] / N
-        const int g = i / GH, c = i - g * GH;
-        const float *w = P + lay.fc1 + c;
-        float acc = 0.f;
-        for (int o = 0; o < LH; ++o) acc = fmaf(w[(size_t)o * GH], avec[g * LH + o], acc);
-        pbar[i] = acc / (float)N;
-    }
-    __syncthreads();
-    for (int i = tid; i < R * GH; i += NT) {
-        const int r = i / GH, c = i - r * GH;
-        Hb[r * HS + c] = pbar[(r / N) * GH + c];
-    }
-    }
-    __syncthreads();
-
-    // P1 = A1^T (1/2 dH . m1), P2 = A2^T (1/2 dH . m2) into U1, U2
-    auto mix_bwd = [&](int l) {
-        const uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
-        for (int i = tid; i < R * GH; i += NT) {
-            const int r = i / GH, c = i - r * GH;
-            const int g = r / N, n = r - g * N;
-            const int nt = c >> 5, bit = c & 31;
-            float p1 = 0.f, p2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const int rj = g * N + j;
-                const float dh = Hb[rj * HS + c] * 0.5f;
-                const float d1 = ((bl[(0 * R + rj) * PRED_NT + nt] >> bit) & 1u) ? dh : 0.f;
-                const float d2 = ((bl[(1 * R + rj) * PRED_NT + nt] >> bit) & 1u) ? dh : 0.f;
-                p1 = fmaf(A1[rj * N + n], d1, p1);
-                p2 = fmaf(A2[rj * N + n], d2, p2);
-            }
-            U1[r * HS + c] = p1;
-            U2[r * HS + c] = p2;
+        for (int i = tid; i < G * hs; i += NT) {   // dpre = w2 (1 - tanh^2)
+            const int g = i / hs, j = i - g * hs;
+            const float t = tv[g * TS + j];
+            tv[g * TS + j] = P[lay.p2_w + j] * (1.f - t * t);
         }
-    };
+        __syncthreads();
+        for (int i = tid; i < G * LH; i += NT) {   // da[o] = sum_j W0[j][nz + o] dpre[j] -> U1[g][0..127]
+            const int g = i / LH, o = i - g * LH;
+            const float *w = P + lay.p0_w + nz + o;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < hs; ++j) acc = fmaf(w[(size_t)j * (nz + LH)], tv[g * TS + j], acc);
+            U1[g * HS + o] = acc;
+        }
+        __syncthreads();
+        // dp = Wfc1^T da  (fc1t [GH][LH]: rows K-contiguous);  dH_L[n][c] = dp[c] / N for every node n
+        run_jobs<LH, 1, PRED_NW>(
+            PRED_NT, U1, HS,
+            [&](int nt, int r, int h, float (&b)[LH / 2]) {
+                const int col = nt * 32 + r;
+                if (col < GH) load_row<LH / 2>(P + lay.fc1t + (size_t)col * LH + h * (LH / 2), b); else zero_row<LH / 2>(b);
+            },
+            id_xf,
+            [&](int, int nt, int r, int h, const f32x16 &acc) {
+                const int col = nt * 32 + r;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int g = acc_row(i, h);
+                    if (g < G && col < GH) {
+                        const float d = acc[i] / (float)N;
+#pragma unroll
+                        for (int n = 0; n < N; ++n) Hb[(g * N + n) * HS + col] = d;
+                    }
+                }
+            });
+    }
+    __syncthreads();
 
     // ---- layers L-1 .. 1 backward: dH_l = P1 W1^T + P2 W2^T  (B rows = W[in][:] K-contiguous) ------
     for (int l = L - 1; l >= 1; --l) {
         if (!(dbg_skip & 32)) mix_bwd(l);
         __syncthreads();
         const float *W1 = P + lay.w1[l], *W2 = P + lay.w2[l];   // [GH in][GH out]
-        f32x16 acc1;
         if (!(dbg_skip & 64)) {
-        run_jobs<GH, 1, PRED_NW>(
-            PRED_NT, U1, HS,
-            [&](int nt, int r, int h, float (&b)[GH / 2]) {
-                const int col = nt * 32 + r;
-                if (col < GH) load_row<GH / 2>(W1 + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
-            },
-            id_xf, [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
-        run_jobs<GH, 1, PRED_NW>(
-            PRED_NT, U2, HS,
-            [&](int nt, int r, int h, float (&b)[GH / 2]) {
-                const int col = nt * 32 + r;
-                if (col < GH) load_row<GH / 2>(W2 + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
-            },
-            id_xf,
-            [&](int, int nt, int r, int h, const f32x16 &acc2) {
-                const int col = nt * 32 + r;
-                if (col < GH) {
+            f32x16 acc1;
+            run_jobs<GH, MT, PRED_NW>(
+                PRED_NT, U1, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W1, nt, r, h, b); }, id_xf,
+                [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
+            run_jobs<GH, MT, PRED_NW>(
+                PRED_NT, U2, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W2, nt, r, h, b); }, id_xf,
+                [&](int mt, int nt, int r, int h, const f32x16 &acc2) {
+                    const int col = nt * 32 + r;
+                    if (col < GH) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) Hb[acc_row(i, h) * HS + col] = acc1[i] + acc2[i];
-                }
-            });
+                        for (int i = 0; i < 16; ++i) Hb[(mt * 32 + acc_row(i, h)) * HS + col] = acc1[i] + acc2[i];
+                    }
+                });
         }
         __syncthreads();
     }
-    // ---- layer 0 backward: dx[r][v] = sum_c P1[r][c] W1[v][c] + P2[r][c] W2[v][c] -------------------
+    // ---- layer 0 backward: dx[r][v] = sum_c P1[r][c] W1[v][c] + P2[r][c] W2[v][c]  (one column tile) ----
     if (!(dbg_skip & 32)) mix_bwd(0);
     __syncthreads();
     if (!(dbg_skip & 128)) {
-        const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]
-        for (int i = tid; i < R * V; i += NT) {
-            const int r = i / V, v = i - r * V;
-            const int g = r / N;
-            float acc = 0.f;
-            for (int c = 0; c < GH; ++c) {
-                acc = fmaf(U1[r * HS + c], W1[v * GH + c], acc);
-                acc = fmaf(U2[r * HS + c], W2[v * GH + c], acc);
-            }
-            if (g0 + g < batch) grad[(size_t)g0 * N * V + i] = acc;
-        }
+        const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]: rows K-contiguous
+        f32x16 acc1;
+        auto load_b0 = [&](const float *W, int r, int h, float (&b)[GH / 2]) {
+            if (r < V) load_row<GH / 2>(W + (size_t)r * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
+        };
+        run_jobs<GH, MT, PRED_NW>(
+            1, U1, HS, [&](int, int r, int h, float (&b)[GH / 2]) { load_b0(W1, r, h, b); }, id_xf,
+            [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
+        run_jobs<GH, MT, PRED_NW>(
+            1, U2, HS, [&](int, int r, int h, float (&b)[GH / 2]) { load_b0(W2, r, h, b); }, id_xf,
+            [&](int mt, int, int r, int h, const f32x16 &acc2) {
+                if (r < V) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int row = mt * 32 + acc_row(i, h);
+                        if (g0 + row / N < batch) grad[((size_t)g0 * N + row) * V + r] = acc1[i] + acc2[i];
+                    }
+                }
+            });
     }
 }
