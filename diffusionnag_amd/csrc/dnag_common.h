@@ -18,6 +18,8 @@ static inline __host__ __device__ size_t align4(size_t x) { return (x + 3) & ~(s
 // Kernel layout of the CATE score network (offsets in floats into the packed blob).
 // Per layer (LayerNorm affine of self_attn.norm / feed_forward.norm folded into Wqkv / W1):
 //   Wqkv'[3d][d] bqkv'[3d] Wo[d][d] bo[d] W1'[dff][d] b1'[dff] W2[d][dff] b2[d] on_g[d] on_b[d]
+// The four matrices are stored FRAGMENT-MAJOR (frag_index below): the 64 lanes of a wave read one
+// contiguous KiB per load instruction instead of 64 separate cache lines.
 // ---------------------------------------------------------------------------------------------
 struct CateLayout {
     int N, V, d, H, dff, L;
@@ -71,15 +73,38 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fragment-major storage of a weight matrix W[rows][K] (rows K-contiguous) that is the B operand of
+// 32x32 MFMA tile jobs: tile nt covers rows nt*32 .. nt*32+31; lane l = 32*h + r of a wave owns row
+// nt*32 + r and the K-half h.  Element e of chunk q of that lane sits at
+//     frag_index = ((nt * (K/8) + q) * 64 + l) * 4 + e      <->   W[nt*32 + r][h*K/2 + 4*q + e]
+// (rows beyond `rows` are zero).  A tile takes 32*K floats.
+// ---------------------------------------------------------------------------------------------
+static inline __host__ __device__ size_t frag_floats(size_t rows, size_t K) { return (rows + 31) / 32 * 32 * K; }
+
+static inline void frag_pack(const float *W, size_t rows, size_t K, size_t ld, float *out) {
+    const size_t ntiles = (rows + 31) / 32, KH = K / 2, NQ = K / 8;
+    for (size_t nt = 0; nt < ntiles; ++nt)
+        for (size_t q = 0; q < NQ; ++q)
+            for (size_t l = 0; l < 64; ++l)
+                for (size_t e = 0; e < 4; ++e) {
+                    const size_t row = nt * 32 + (l & 31), k = (l >> 5) * KH + 4 * q + e;
+                    out[((nt * NQ + q) * 64 + l) * 4 + e] = row < rows ? W[row * ld + k] : 0.f;
+                }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Kernel layout of the MetaNeuralPredictor surrogate.
-//   gcn l: W1 [in][g], W2 [in][g] (reference layout, used by the backward pass as B[k=out][col=in]^T,
-//          i.e. row `in` is K-contiguous over `out`) and W1t [g][in], W2t [g][in] (forward pass).
+//   gcn 0: W1, W2 [V][g] plain (forward on FMAs);
+//   gcn l: w1b/w2b = fragment-major W[in][out] (backward: dH_l = P W^T sums over `out`),
+//          w1f/w2f = fragment-major W^T[out][in] (forward, l >= 1);
+//   fc1f = fragment-major fc1 [lh][g] (a = fc1 p), fc1b = fragment-major fc1^T [g][lh] (dp = fc1^T da).
 // ---------------------------------------------------------------------------------------------
 #define DNAG_MAX_GCN 8
 struct PredLayout {
     int N, V, g, L, lh, hs, nz;
-    size_t w1[DNAG_MAX_GCN], w2[DNAG_MAX_GCN], w1t[DNAG_MAX_GCN], w2t[DNAG_MAX_GCN];
-    size_t fc1, fc1t;             // fc1 [lh][g], fc1t [g][lh]
+    size_t w1_0, w2_0;            // gcn.0 weights [V][g], plain
+    size_t w1b[DNAG_MAX_GCN], w2b[DNAG_MAX_GCN], w1f[DNAG_MAX_GCN], w2f[DNAG_MAX_GCN];
+    size_t fc1f, fc1b;
     size_t t1_w, t1_b, t2_w, t2_b;  // [4g][g],[4g],[g][4g],[g]
     size_t p0_w, p0_b;            // pred_fc.0 [hs][nz+lh], [hs]
     size_t p0_at;                 // transposed arch part [lh][hs]
@@ -94,15 +119,17 @@ static inline __host__ __device__ PredLayout pred_layout(const dnag_pred_dims &c
     y.hs = c.hs; y.nz = c.nz;
     const size_t g = y.g, lh = y.lh, hs = y.hs, nz = y.nz;
     size_t o = 0;
+    y.w1_0 = o; o += align4((size_t)y.V * g);
+    y.w2_0 = o; o += align4((size_t)y.V * g);
     for (int l = 0; l < y.L && l < DNAG_MAX_GCN; ++l) {
         const size_t in = l == 0 ? (size_t)y.V : g;
-        y.w1[l] = o; o += align4(in * g);
-        y.w2[l] = o; o += align4(in * g);
-        y.w1t[l] = o; o += align4(in * g);
-        y.w2t[l] = o; o += align4(in * g);
+        y.w1b[l] = o; o += frag_floats(in, g);
+        y.w2b[l] = o; o += frag_floats(in, g);
+        y.w1f[l] = o; o += l == 0 ? 0 : frag_floats(g, in);
+        y.w2f[l] = o; o += l == 0 ? 0 : frag_floats(g, in);
     }
-    y.fc1 = o; o += lh * g;
-    y.fc1t = o; o += lh * g;
+    y.fc1f = o; o += frag_floats(lh, g);
+    y.fc1b = o; o += frag_floats(g, lh);
     y.t1_w = o; o += 4 * g * g;
     y.t1_b = o; o += 4 * g;
     y.t2_w = o; o += 4 * g * g;

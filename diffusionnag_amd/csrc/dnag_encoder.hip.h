@@ -58,6 +58,17 @@ __device__ __forceinline__ void load_row(const float *p, float (&b)[KH]) {
         b[4 * i + 0] = v.x; b[4 * i + 1] = v.y; b[4 * i + 2] = v.z; b[4 * i + 3] = v.w;
     }
 }
+// B fragments of column tile `nt` from a fragment-major matrix (dnag_common.h: frag_index): every
+// load instruction of the wave reads one contiguous KiB.
+template <int K>
+__device__ __forceinline__ void load_frag(const float *F, int nt, float (&b)[K / 2]) {
+    const float *p = F + ((size_t)nt * (K / 8) * 64 + (threadIdx.x & 63)) * 4;
+#pragma unroll
+    for (int q = 0; q < K / 8; ++q) {
+        const v4f v = *reinterpret_cast<const v4f *>(p + (size_t)q * 256);
+        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+    }
+}
 template <int KH>
 __device__ __forceinline__ void zero_row(float (&b)[KH]) {
 #pragma unroll
@@ -186,7 +197,6 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fh = lane >> 5;
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
 
@@ -195,9 +205,8 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     // The weights are const __restrict__, so the compiler may hoist these loads above barriers and then
     // spill them; passing the address through an opaque asm pins the issue point of every prefetch.
     auto load_w64 = [&](const float *W, int nt, float (&b)[D / 2]) {
-        const float *w = W + (size_t)(nt * 32 + fr) * D + fh * (D / 2);
-        asm volatile("" : "+v"(w));
-        load_row<D / 2>(w, b);
+        asm volatile("" : "+s"(W));
+        load_frag<D>(W, nt, b);
     };
     const int ft_qkv = JobSplit<NT_QKV, MT, 4>::first_tile(wave);
     const int ft_o = JobSplit<NT_O, MT, 4>::first_tile(wave);
@@ -205,6 +214,11 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     const int ft_f2 = JobSplit<NT_F2, MT, 4>::first_tile(wave);
     if (ft_qkv >= 0) load_w64(P + lay.layer0 + lay.l_wqkv, ft_qkv, bP);
 
+    {   // debug stagger experiment: bits 8-9 select which blocks sleep, bits 10-17 how long (x 8K cycles / 16)
+        const int mode = (dbg_skip >> 8) & 3, amt = (dbg_skip >> 10) & 255;
+        const int sel = mode == 1 ? (blockIdx.x >> 8) & 1 : mode == 2 ? (blockIdx.x >> 3) & 1 : mode == 3 ? (blockIdx.x >> 4) & 1 : 0;
+        if (sel) for (int i = 0; i < amt; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     // ---- stage inputs -------------------------------------------------------------------------
     float *xin = qkv;                   // [R][V] alias
     for (int i = tid; i < R * V; i += 256) {
@@ -238,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         }
     }
     __syncthreads();
+    if (dbg_skip & 128) return;
 
     for (int l = 0; l < L; ++l) {
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
@@ -322,9 +337,9 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         }
         if (ft_f1 >= 0) load_w64(LP + lay.l_w1, ft_f1, bQ);
         if (ft_f2 >= 0) {
-            const float *w = LP + lay.l_w2 + (size_t)(ft_f2 * 32 + fr) * DFF + fh * (DFF / 2);
-            asm volatile("" : "+v"(w));
-            load_row<DFF / 2>(w, bR);
+            const float *w = LP + lay.l_w2;
+            asm volatile("" : "+s"(w));
+            load_frag<DFF>(w, ft_f2, bR);
         }
         __syncthreads();
         // ---- hidden = relu(LN2(h) W1'^T + b1') -----------------------------------------------------
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
             const float *W = LP + lay.l_w2, *bias = LP + lay.l_b2;
             run_jobs2<DFF, NT_F2, MT, 4, false>(
                 qkv, QS, bR, bR,
-                [&](int nt, int r, int h, float (&b)[DFF / 2]) { load_row<DFF / 2>(W + (size_t)(nt * 32 + r) * DFF + h * (DFF / 2), b); },
+                [&](int nt, int, int, float (&b)[DFF / 2]) { load_frag<DFF>(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
                     const float bv = bias[col];

@@ -10,12 +10,18 @@
 
 #define GEMM_BM 128
 #define GEMM_BN 128
+#ifndef GEMM_BK
 #define GEMM_BK 32
-#define GEMM_LS (GEMM_BK + 4)   // LDS row stride (floats): 36 -> conflict-free ds_read_b128
+#endif
+#define GEMM_LS (GEMM_BK + 4)   // LDS row stride (floats): 20 or 36 -> conflict-free ds_read_b128
+#define GEMM_TPR (GEMM_BK / 4)  // threads per tile row (one 16-byte load each)
+#define GEMM_RPP (256 / GEMM_TPR)   // rows per staging pass
+#define GEMM_NP (GEMM_BM / GEMM_RPP)  // staging passes per operand
+#define GEMM_OCC (GEMM_BK == 16 ? 3 : 2)
 
 // A [M][K] row-major (M % 128 == 0), W [Nout][K] row-major (Nout % 128 == 0), K % 32 == 0.
 template <bool ELU, int TAG>
-__global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(const float *__restrict__ A, const float *__restrict__ W,
+__global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                                const float *__restrict__ bias, float *__restrict__ C,
                                                                int M, int Nout, int K) {
     __shared__ __attribute__((aligned(16))) float As[2][GEMM_BM * GEMM_LS];
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(const float *__re
     const int wg = ((xcd < r8) ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
     const int tm = wg / nbn, tn = wg - tm * nbn;
 
-    const int lrow = tid >> 3, lk = (tid & 7) * 4;
+    const int lrow = tid / GEMM_TPR, lk = (tid % GEMM_TPR) * 4;
     const float *Ag = A + (size_t)(tm * GEMM_BM + lrow) * K + lk;
     const float *Wg = W + (size_t)(tn * GEMM_BN + lrow) * K + lk;
 
@@ -44,52 +50,57 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(const float *__re
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    v4f ra[4], rb[4];
+    // Pipeline: tile kt+1 sits in registers while tile kt is consumed from LDS; it is written to the
+    // other LDS buffer at the START of iteration kt (its loads had a whole iteration to land) and the
+    // loads of tile kt+2 are issued right after, so neither the global latency nor the ds_write burst
+    // sits between the last MFMA of a tile and the barrier.
+    v4f ra[GEMM_NP], rb[GEMM_NP];
     const int KT = K / GEMM_BK;
+    auto gload = [&](int kt) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(32 * p) * K);
-        rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(32 * p) * K);
-    }
+        for (int p = 0; p < GEMM_NP; ++p) {
+            ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(GEMM_RPP * p) * K + kt * GEMM_BK);
+            rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(GEMM_RPP * p) * K + kt * GEMM_BK);
+        }
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        *reinterpret_cast<v4f *>(&As[0][(lrow + 32 * p) * GEMM_LS + lk]) = ra[p];
-        *reinterpret_cast<v4f *>(&Bs[0][(lrow + 32 * p) * GEMM_LS + lk]) = rb[p];
-    }
+        for (int p = 0; p < GEMM_NP; ++p) {
+            *reinterpret_cast<v4f *>(&As[buf][(lrow + GEMM_RPP * p) * GEMM_LS + lk]) = ra[p];
+            *reinterpret_cast<v4f *>(&Bs[buf][(lrow + GEMM_RPP * p) * GEMM_LS + lk]) = rb[p];
+        }
+    };
+    gload(0);
+    lstore(0);
+    if (KT > 1) gload(1);
     __syncthreads();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < KT) {
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(32 * p) * K + (kt + 1) * GEMM_BK);
-                rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(32 * p) * K + (kt + 1) * GEMM_BK);
-            }
-        }
+        if (kt + 1 < KT) lstore(cur ^ 1);
+        if (kt + 2 < KT) gload(kt + 2);
         const float *as = &As[cur][(wm * 64 + r) * GEMM_LS + 4 * h];
         const float *bs = &Bs[cur][(wn * 64 + r) * GEMM_LS + 4 * h];
+        v4f fa[2][2], fb[2][2];   // [ping-pong][tile]
+        fa[0][0] = *reinterpret_cast<const v4f *>(as);
+        fa[0][1] = *reinterpret_cast<const v4f *>(as + 32 * GEMM_LS);
+        fb[0][0] = *reinterpret_cast<const v4f *>(bs);
+        fb[0][1] = *reinterpret_cast<const v4f *>(bs + 32 * GEMM_LS);
 #pragma unroll
         for (int kc = 0; kc < GEMM_BK / 8; ++kc) {
-            const v4f a0 = *reinterpret_cast<const v4f *>(as + kc * 8);
-            const v4f a1 = *reinterpret_cast<const v4f *>(as + 32 * GEMM_LS + kc * 8);
-            const v4f b0 = *reinterpret_cast<const v4f *>(bs + kc * 8);
-            const v4f b1 = *reinterpret_cast<const v4f *>(bs + 32 * GEMM_LS + kc * 8);
-            acc[0][0] = mfma32(a0.x, b0.x, acc[0][0]); acc[0][1] = mfma32(a0.x, b1.x, acc[0][1]);
-            acc[1][0] = mfma32(a1.x, b0.x, acc[1][0]); acc[1][1] = mfma32(a1.x, b1.x, acc[1][1]);
-            acc[0][0] = mfma32(a0.y, b0.y, acc[0][0]); acc[0][1] = mfma32(a0.y, b1.y, acc[0][1]);
-            acc[1][0] = mfma32(a1.y, b0.y, acc[1][0]); acc[1][1] = mfma32(a1.y, b1.y, acc[1][1]);
-            acc[0][0] = mfma32(a0.z, b0.z, acc[0][0]); acc[0][1] = mfma32(a0.z, b1.z, acc[0][1]);
-            acc[1][0] = mfma32(a1.z, b0.z, acc[1][0]); acc[1][1] = mfma32(a1.z, b1.z, acc[1][1]);
-            acc[0][0] = mfma32(a0.w, b0.w, acc[0][0]); acc[0][1] = mfma32(a0.w, b1.w, acc[0][1]);
-            acc[1][0] = mfma32(a1.w, b0.w, acc[1][0]); acc[1][1] = mfma32(a1.w, b1.w, acc[1][1]);
-        }
-        if (kt + 1 < KT) {
-            const int nxt = cur ^ 1;
+            const int c = kc & 1, n = c ^ 1;
+            if (kc + 1 < GEMM_BK / 8) {
+                fa[n][0] = *reinterpret_cast<const v4f *>(as + (kc + 1) * 8);
+                fa[n][1] = *reinterpret_cast<const v4f *>(as + 32 * GEMM_LS + (kc + 1) * 8);
+                fb[n][0] = *reinterpret_cast<const v4f *>(bs + (kc + 1) * 8);
+                fb[n][1] = *reinterpret_cast<const v4f *>(bs + 32 * GEMM_LS + (kc + 1) * 8);
+            }
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *reinterpret_cast<v4f *>(&As[nxt][(lrow + 32 * p) * GEMM_LS + lk]) = ra[p];
-                *reinterpret_cast<v4f *>(&Bs[nxt][(lrow + 32 * p) * GEMM_LS + lk]) = rb[p];
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = mfma32(fa[c][0][e], fb[c][0][e], acc[0][0]);
+                acc[0][1] = mfma32(fa[c][0][e], fb[c][1][e], acc[0][1]);
+                acc[1][0] = mfma32(fa[c][1][e], fb[c][0][e], acc[1][0]);
+                acc[1][1] = mfma32(fa[c][1][e], fb[c][1][e], acc[1][1]);
             }
         }
         __syncthreads();
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bias_act_kernel(const float *__re
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float v = acc[i][j][e] + bv;
-                if (ELU) v = elu1(v);
+                if (ELU) v = v > 0.f ? v : __expf(v) - 1.0f;   // elu: exp(x) - 1 on the hardware exponential
                 C[(size_t)(row0 + acc_row(e, h)) * Nout + col] = v;
             }
         }

@@ -107,18 +107,21 @@ extern "C" int dnag_cate_pack(const dnag_cate_dims *c, const float *s, const flo
             bo[r] = (float)acc;
         }
     };
+    std::vector<float> tmp((3 * d > dff ? 3 * d : dff) * d);
     for (size_t l = 0; l < L; ++l) {
         float *LP = out + y.layer0 + l * y.layer_stride;
         const float *ln1g = s + o, *ln1b = s + o + d; o += 2 * d;
         for (int j = 0; j < 3; ++j) {   // Q, K, V
-            fold(s + o, s + o + d * d, ln1g, ln1b, d, LP + y.l_wqkv + j * d * d, LP + y.l_bqkv + j * d);
+            fold(s + o, s + o + d * d, ln1g, ln1b, d, tmp.data() + j * d * d, LP + y.l_bqkv + j * d);
             o += d * d + d;
         }
-        memcpy(LP + y.l_wo, s + o, d * d * sizeof(float)); o += d * d;
+        frag_pack(tmp.data(), 3 * d, d, d, LP + y.l_wqkv);
+        frag_pack(s + o, d, d, d, LP + y.l_wo); o += d * d;
         memcpy(LP + y.l_bo, s + o, d * sizeof(float)); o += d;
         const float *ln2g = s + o, *ln2b = s + o + d; o += 2 * d;
-        fold(s + o, s + o + dff * d, ln2g, ln2b, dff, LP + y.l_w1, LP + y.l_b1); o += dff * d + dff;
-        memcpy(LP + y.l_w2, s + o, d * dff * sizeof(float)); o += d * dff;
+        fold(s + o, s + o + dff * d, ln2g, ln2b, dff, tmp.data(), LP + y.l_b1); o += dff * d + dff;
+        frag_pack(tmp.data(), dff, d, d, LP + y.l_w1);
+        frag_pack(s + o, d, dff, dff, LP + y.l_w2); o += d * dff;
         memcpy(LP + y.l_b2, s + o, d * sizeof(float)); o += d;
     }
     for (size_t l = 0; l < L; ++l) {   // encoder_f.norms.l
@@ -150,22 +153,26 @@ extern "C" int dnag_pred_pack(const dnag_pred_dims *c, const float *s, const flo
     const size_t g = y.g, lh = y.lh, hs = y.hs, nz = y.nz;
     memset(out, 0, y.total * sizeof(float));
     size_t o = 0;
+    std::vector<float> tr(g * (g > lh ? g : lh));
     for (int l = 0; l < y.L; ++l) {
         const size_t in = l == 0 ? (size_t)y.V : g;
         for (int w = 0; w < 2; ++w) {
             const float *W = s + o; o += in * g;   // [in][g]
-            float *dst = out + (w ? y.w2[l] : y.w1[l]);
-            float *dstt = out + (w ? y.w2t[l] : y.w1t[l]);
-            memcpy(dst, W, in * g * sizeof(float));
-            for (size_t i = 0; i < in; ++i)
-                for (size_t k = 0; k < g; ++k) dstt[k * in + i] = W[i * g + k];
+            if (l == 0) memcpy(out + (w ? y.w2_0 : y.w1_0), W, in * g * sizeof(float));
+            frag_pack(W, in, g, g, out + (w ? y.w2b[l] : y.w1b[l]));
+            if (l > 0) {
+                for (size_t i = 0; i < in; ++i)
+                    for (size_t k = 0; k < g; ++k) tr[k * in + i] = W[i * g + k];
+                frag_pack(tr.data(), g, in, in, out + (w ? y.w2f[l] : y.w1f[l]));
+            }
         }
     }
     {
         const float *W = s + o; o += lh * g;   // fc1 [lh][g]
-        memcpy(out + y.fc1, W, lh * g * sizeof(float));
+        frag_pack(W, lh, g, g, out + y.fc1f);
         for (size_t i = 0; i < lh; ++i)
-            for (size_t k = 0; k < g; ++k) out[y.fc1t + k * lh + i] = W[i * g + k];
+            for (size_t k = 0; k < g; ++k) tr[k * lh + i] = W[i * g + k];
+        frag_pack(tr.data(), g, lh, lh, out + y.fc1b);
     }
     memcpy(out + y.t1_w, s + o, 4 * g * g * sizeof(float)); o += 4 * g * g;
     memcpy(out + y.t1_b, s + o, 4 * g * sizeof(float)); o += 4 * g;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             ux2[i] = u2;
         }
         __syncthreads();
-        const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]
+        const float *W1 = P + lay.w1_0, *W2 = P + lay.w2_0;   // [V][GH]
         for (int i = tid; i < R * GH; i += NT) {
             const int r = i / GH, c = i - r * GH;
             float z1 = 0.f, z2 = 0.f;
@@ -204,16 +204,15 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             }
         }
     };
-    auto load_b144 = [&](const float *W, int nt, int r, int h, float (&b)[GH / 2]) {   // rows of W are K-contiguous
-        const int col = nt * 32 + r;
-        if (col < GH) load_row<GH / 2>(W + (size_t)col * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
+    auto load_b144 = [&](const float *F, int nt, int, int, float (&b)[GH / 2]) {   // fragment-major, zero padded
+        load_frag<GH>(F, nt, b);
     };
 
     // ---- layers 1 .. L-1 forward -----------------------------------------------------------------
     for (int l = 1; l < L; ++l) {
         if (!(dbg_skip & 2)) mix_fwd();
         __syncthreads();
-        const float *W1t = P + lay.w1t[l], *W2t = P + lay.w2t[l];   // [GH out][GH in]
+        const float *W1t = P + lay.w1f[l], *W2t = P + lay.w2f[l];   // fragment-major W^T [out][in]
         uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
         if (!(dbg_skip & 4)) {
             f32x16 acc1;
@@ -254,7 +253,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         // a = Wfc1 p  (fc1 [LH][GH]: rows K-contiguous) -> U2[g][0..127]
         run_jobs<GH, 1, PRED_NW>(
             LH / 32, U1, HS,
-            [&](int nt, int r, int h, float (&b)[GH / 2]) { load_row<GH / 2>(P + lay.fc1 + (size_t)(nt * 32 + r) * GH + h * (GH / 2), b); },
+            [&](int nt, int, int, float (&b)[GH / 2]) { load_frag<GH>(P + lay.fc1f, nt, b); },
             id_xf,
             [&](int, int nt, int r, int h, const f32x16 &acc) {
 #pragma unroll
@@ -302,10 +301,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         // dp = Wfc1^T da  (fc1t [GH][LH]: rows K-contiguous);  dH_L[n][c] = dp[c] / N for every node n
         run_jobs<LH, 1, PRED_NW>(
             PRED_NT, U1, HS,
-            [&](int nt, int r, int h, float (&b)[LH / 2]) {
-                const int col = nt * 32 + r;
-                if (col < GH) load_row<LH / 2>(P + lay.fc1t + (size_t)col * LH + h * (LH / 2), b); else zero_row<LH / 2>(b);
-            },
+            [&](int nt, int, int, float (&b)[LH / 2]) { load_frag<LH>(P + lay.fc1b, nt, b); },
             id_xf,
             [&](int, int nt, int r, int h, const f32x16 &acc) {
                 const int col = nt * 32 + r;
@@ -326,7 +322,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     for (int l = L - 1; l >= 1; --l) {
         if (!(dbg_skip & 32)) mix_bwd(l);
         __syncthreads();
-        const float *W1 = P + lay.w1[l], *W2 = P + lay.w2[l];   // [GH in][GH out]
+        const float *W1 = P + lay.w1b[l], *W2 = P + lay.w2b[l];   // fragment-major W [in][out]
         if (!(dbg_skip & 64)) {
             f32x16 acc1;
             run_jobs<GH, MT, PRED_NW>(
@@ -348,16 +344,13 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     if (!(dbg_skip & 32)) mix_bwd(0);
     __syncthreads();
     if (!(dbg_skip & 128)) {
-        const float *W1 = P + lay.w1[0], *W2 = P + lay.w2[0];   // [V][GH]: rows K-contiguous
+        const float *W1 = P + lay.w1b[0], *W2 = P + lay.w2b[0];   // fragment-major [V -> 32][GH], one tile
         f32x16 acc1;
-        auto load_b0 = [&](const float *W, int r, int h, float (&b)[GH / 2]) {
-            if (r < V) load_row<GH / 2>(W + (size_t)r * GH + h * (GH / 2), b); else zero_row<GH / 2>(b);
-        };
         run_jobs<GH, MT, PRED_NW>(
-            1, U1, HS, [&](int, int r, int h, float (&b)[GH / 2]) { load_b0(W1, r, h, b); }, id_xf,
+            1, U1, HS, [&](int, int, int, float (&b)[GH / 2]) { load_frag<GH>(W1, 0, b); }, id_xf,
             [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
         run_jobs<GH, MT, PRED_NW>(
-            1, U2, HS, [&](int, int r, int h, float (&b)[GH / 2]) { load_b0(W2, r, h, b); }, id_xf,
+            1, U2, HS, [&](int, int, int, float (&b)[GH / 2]) { load_frag<GH>(W2, 0, b); }, id_xf,
             [&](int mt, int, int r, int h, const f32x16 &acc2) {
                 if (r < V) {
 #pragma unroll

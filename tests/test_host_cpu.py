@@ -22,6 +22,15 @@ from tests.helpers import predictor_config, score_config
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def unfrag(flat, rows, K):
+    """Inverse of frag_pack (csrc/dnag_common.h): fragment-major floats -> W[rows][K]."""
+    nt_all = (rows + 31) // 32
+    a = np.asarray(flat[: nt_all * 32 * K]).reshape(nt_all, K // 8, 2, 32, 4)      # [nt][q][h][r][e]
+    W = a.transpose(0, 3, 2, 1, 4).reshape(nt_all * 32, K)                          # row = nt*32+r ; k = h*K/2 + 4q + e
+    assert not W[rows:].any()
+    return W[:rows]
+
+
 def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     assert lib.dnag_abi_version() == 1
@@ -81,7 +90,7 @@ def test_cate_pack_folds_layernorm_into_linear():
     h = rs.standard_normal((5, d))
     for l in (0, 7):
         base = layer0 + l * stride
-        Wqkv = packed[base: base + 3 * d * d].reshape(3 * d, d)
+        Wqkv = unfrag(packed[base: base + 3 * d * d], 3 * d, d)
         bqkv = packed[base + 3 * d * d: base + 3 * d * d + 3 * d]
         p = f"graph_encoder.encoder_f.layers.{l}.self_attn"
         g, b = sd[p + ".norm.weight"].double().numpy(), sd[p + ".norm.bias"].double().numpy()
@@ -111,11 +120,13 @@ def test_predictor_pack_transposes():
     g = 144
     w1_0 = packed[: 7 * g].reshape(7, g)
     assert np.array_equal(w1_0, sdp["gcn.0.weight1"].numpy())
-    off = 4 * (7 * g + 0)   # 7*144 = 1008 is a multiple of 4: w1, w2, w1t, w2t of layer 0
-    w1_1 = packed[off: off + g * g].reshape(g, g)
-    w1t_1 = packed[off + 2 * g * g: off + 3 * g * g].reshape(g, g)
-    assert np.array_equal(w1_1, sdp["gcn.1.weight1"].numpy())
-    assert np.array_equal(w1t_1, sdp["gcn.1.weight1"].numpy().T)
+    off = 2 * 7 * g                                   # w1_0, w2_0 plain; then per layer w1b, w2b, (w1f, w2f)
+    assert np.array_equal(unfrag(packed[off:], 7, g), sdp["gcn.0.weight1"].numpy())       # layer 0 backward tile
+    off += 2 * 32 * g                                 # layer 0: two one-tile matrices
+    w1b_1 = unfrag(packed[off:], g, g)
+    w1f_1 = unfrag(packed[off + 2 * 160 * g:], g, g)
+    assert np.array_equal(w1b_1, sdp["gcn.1.weight1"].numpy())
+    assert np.array_equal(w1f_1, sdp["gcn.1.weight1"].numpy().T)
     # set encoder (PyTorch, once per call) equals the oracle's restatement
     task = synthetic.synthetic_task(10, 20, seed=2)
     with torch.no_grad():
