@@ -132,6 +132,61 @@ def predictor_param_spec(dims: PredictorDims = PredictorDims()) -> Spec:
     return s
 
 
+@dataclass(frozen=True)
+class PredictorCateDims:
+    """Shape hyper-parameters of MetaPredictorCATE, the OFA surrogate (SURVEY.md section 5.1;
+    reference MobileNetV3/configs/tr_meta_surrogate_ofa.py:112-145)."""
+    max_node: int = 20
+    n_vocab: int = 9
+    d_model: int = 64
+    n_head: int = 2
+    d_ff: int = 32
+    n_layers: int = 2
+    hs: int = 512
+    nz: int = 56
+    num_sample: int = 20
+    set_heads: int = 4
+
+    @property
+    def fdim(self) -> int:
+        return self.n_layers * self.d_model
+
+    @property
+    def rdim(self) -> int:
+        return self.max_node * self.n_vocab
+
+
+def predictor_cate_param_spec(dims: PredictorCateDims = PredictorCateDims()) -> Spec:
+    """``MetaPredictorCATE.state_dict()`` names/shapes in order (reference cate.py:253-305)."""
+    d, ff, V, nz = dims.d_model, dims.d_ff, dims.n_vocab, dims.nz
+    s: Spec = []
+    s += _linear("opEmb.fc", d, V)
+    s += _linear("timeEmb1", 4 * d, d)
+    s += _linear("timeEmb2", d, 4 * d)
+    for l in range(dims.n_layers):
+        p = f"graph_encoder.encoder_f.layers.{l}"
+        s += _layernorm(p + ".self_attn.norm", d)
+        for j in range(4):
+            s += _linear(p + f".self_attn.attn.linears.{j}", d, d)
+        s += _layernorm(p + ".feed_forward.norm", d)
+        s += _linear(p + ".feed_forward.feed_forward.w_1", ff, d)
+        s += _linear(p + ".feed_forward.feed_forward.w_2", d, ff)
+    for l in range(dims.n_layers):
+        s += _layernorm(f"graph_encoder.encoder_f.norms.{l}", d)
+    F, R = dims.fdim, dims.rdim
+    s += _linear("final.linears.0", 2 * F, F)
+    s += _linear("final.linears.1", 2 * F, 2 * F)
+    s += _linear("final.linears.2", V, 2 * F)
+    s += _linear("regeress.linears.0", 2 * R, R)
+    s += _linear("regeress.linears.1", 2 * R, 2 * R)
+    s += _setpool("intra_setpool", 512, nz)
+    s += _setpool("inter_setpool", nz, nz)
+    s += _linear("set_fc.0", nz, 512)
+    s += _linear("pred_fc.0", dims.hs, nz + 2 * R)
+    s += _linear("pred_fc.2", 1, dims.hs)
+    return s
+
+
 def n_params(spec: Spec) -> int:
     n = 0
     for _, shape, _ in spec:

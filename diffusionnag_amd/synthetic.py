@@ -19,8 +19,8 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from .specs import (CateDims, PredictorDims, Spec, cate_param_spec,
-                    predictor_param_spec)
+from .specs import (CateDims, PredictorCateDims, PredictorDims, Spec, cate_param_spec,
+                    predictor_cate_param_spec, predictor_param_spec)
 
 
 def _draw(rs: np.random.RandomState, shape, init) -> np.ndarray:
@@ -69,6 +69,20 @@ def cate_state_dict(dims: CateDims = CateDims(), seed: int = 0, preset: str = "d
 
 def predictor_state_dict(dims: PredictorDims = PredictorDims(), seed: int = 1):
     return state_dict_from_spec(predictor_param_spec(dims), seed)
+
+
+def predictor_cate_state_dict(dims: PredictorCateDims = PredictorCateDims(), seed: int = 5, perturb_norms: bool = True):
+    """Random-init MetaPredictorCATE (OFA surrogate) weights; LayerNorm affine perturbed by default."""
+    sd = state_dict_from_spec(predictor_cate_param_spec(dims), seed)
+    if perturb_norms:
+        rs = np.random.RandomState(seed + 7919)
+        for k in sd:
+            if ".norm" in k or ".norms." in k:
+                if k.endswith(".weight"):
+                    sd[k] = torch.from_numpy((1.0 + 0.2 * rs.uniform(-1, 1, sd[k].shape)).astype(np.float32))
+                else:
+                    sd[k] = torch.from_numpy((0.1 * rs.uniform(-1, 1, sd[k].shape)).astype(np.float32))
+    return sd
 
 
 def nb201_adjacency() -> torch.Tensor:

@@ -272,6 +272,33 @@ def classifier_grad(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tensor, l
 
 
 # ----------------------------------------------------------------------------------------------
+# MetaPredictorCATE, the OFA surrogate (models/cate.py:251-360) and its guidance gradient
+# ----------------------------------------------------------------------------------------------
+
+def predictor_cate_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, D_mu: Tensor, *,
+                           n_layers: int = 2, n_head: int = 2) -> Tensor:
+    """MetaPredictorCATE.forward with cached D_mu: arch_encode (cate.py:311-327: embedding WITHOUT
+    positional encoding, encoder, `final` MLP, flatten, `regeress` MLP) then predict (:341-348)."""
+    d = sd["opEmb.fc.weight"].shape[0]
+    B = X.shape[0]
+    emb = _lin(sd, "opEmb.fc", X) * math.sqrt(d) + time_mlp(sd, time_cond, d).unsqueeze(1)   # :312-320
+    hs = encoder_stack(sd, "graph_encoder.encoder_f", emb, maskX, n_layers, n_head)
+    h = mlp_head(sd, "final", torch.cat(hs, dim=-1), 3)                          # :323
+    h = mlp_head(sd, "regeress", h.reshape(B, -1), 2)                            # :325-326
+    vec = torch.cat([D_mu.reshape(1, -1).expand(B, -1), h], dim=1)               # :342-347
+    return _lin(sd, "pred_fc.2", torch.tanh(_lin(sd, "pred_fc.0", vec)))         # :348
+
+
+def classifier_grad_cate(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tensor, labels: str = "max") -> Tensor:
+    """models/utils.py:130-145 (regress=True) for the OFA surrogate."""
+    with torch.enable_grad():
+        x_in = x.detach().clone().requires_grad_(True)
+        logit = predictor_cate_forward(sd, x_in, t * 999, maskX, D_mu)
+        prob = logit.sum() if labels == "max" else -logit.sum()
+        return torch.autograd.grad(prob, x_in)[0]
+
+
+# ----------------------------------------------------------------------------------------------
 # predictor-corrector loop (sampling.py:203-256, :424-445, :496-577)
 # ----------------------------------------------------------------------------------------------
 
@@ -297,7 +324,8 @@ def pc_sample(score_sd: SD, sde: VPSDE, mask: Tensor, tape: dict, *, eps: float 
         s = score_fn(score_sd, sde, x, vec_t, maskX, **kw)
         if pred_sd is None:
             return s, s, None
-        cg = classifier_grad(pred_sd, x, vec_t, maskX, D_mu, labels)
+        grad_fn = classifier_grad_cate if "regeress.linears.0.weight" in pred_sd else classifier_grad
+        cg = grad_fn(pred_sd, x, vec_t, maskX, D_mu, labels)
         return s + classifier_scale * cg, s, cg
 
     x_mean = x

@@ -131,3 +131,46 @@ def test_pc_full_n1000_guided_contractive(golden):
     close(final, g["final"], 0, 1e-4 * np.abs(g["final"]).max())
     q, qr = O.quantize(final.clone()), O.quantize(T(g["final"]).clone())
     assert torch.equal(q, qr)
+
+
+# ----------------------------------------------------------------------------------------------------
+# OFA (20 x 9) surrogate MetaPredictorCATE and the guided OFA sampler (tests/golden/make_golden_ofa.py)
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mname", ["chain", "random"])
+def test_predictor_cate_and_guidance_gradient(golden, mname):
+    from diffusionnag_amd.specs import PredictorCateDims
+    g = golden(f"predictor_ofa_{mname}")
+    sdp = synthetic.predictor_cate_state_dict(PredictorCateDims(), seed=int(g["seed"]))
+    task = synthetic.synthetic_task(10, 20, seed=int(g["task_seed"]))
+    D_mu = O.set_encode(sdp, task)
+    close(D_mu, g["D_mu"], 1e-5, 1e-6)
+    X, mask = T(g["X"]), T(g["mask"])
+    mB = mask.unsqueeze(0).repeat(X.shape[0], 1, 1)
+    for i, tval in enumerate(g["t"]):
+        t = torch.ones(X.shape[0]) * float(tval)
+        close(O.predictor_cate_forward(sdp, X, t * 999, mB, D_mu), g["y"][i], 1e-5, 1e-6)
+        close(O.classifier_grad_cate(sdp, X, t, mB, D_mu, "max"), g["grad"][i], 1e-4, 2e-6 * np.abs(g["grad"][i]).max())
+
+
+@pytest.mark.parametrize("name", ["pc_guided_ofa_n1000_first6", "pc_guided_ofa_contractive_n50"])
+def test_pc_guided_ofa(golden, name):
+    from diffusionnag_amd.specs import PredictorCateDims
+    g = golden(name)
+    dims = CateDims(max_node=20, n_vocab=9, stagewise_pos=True)
+    sd = synthetic.cate_state_dict(dims, seed=int(g["seed"]), preset=str(g["preset"]))
+    sdp = synthetic.predictor_cate_state_dict(PredictorCateDims(), seed=int(g["pred_seed"]))
+    sde = O.VPSDE(0.1, float(g["beta_max"]), int(g["sde_N"]))
+    B, S = int(g["B"]), int(g["n_run"])
+    tape = synthetic.noise_tape(S, (B, 20, 9), int(g["tape_seed"]))
+    rec = []
+    final = O.pc_sample(sd, sde, T(g["mask"]), tape, eps=float(g["eps"]), snr=float(g["snr"]), n_steps=S, pred_sd=sdp,
+                        D_mu=O.set_encode(sdp, synthetic.synthetic_task(10, 20, seed=2)),
+                        classifier_scale=float(g["classifier_scale"]), record=rec, model_kw=dict(stagewise_pos=True))
+    for i in sorted({0, 1, S // 2, S - 1}):
+        sc = np.abs(g["x_pred"][i]).max()
+        close(rec[i]["x_pred"], g["x_pred"][i], 0, 2e-4 * sc)
+        close(rec[i]["score_p"], g["score_p"][i], 0, 2e-4 * np.abs(g["score_p"][i]).max())
+        close(rec[i]["cgrad_c"], g["cgrad_c"][i], 0, 1e-3 * np.abs(g["cgrad_c"][i]).max())
+    if "final" in g:
+        close(final, g["final"], 0, 2e-4 * np.abs(g["final"]).max())
+        assert torch.equal(O.quantize(final.clone()), O.quantize(T(g["final"]).clone()))
