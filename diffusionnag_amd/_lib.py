@@ -24,7 +24,9 @@ EXPORTS = (
     "dnag_abi_version", "dnag_last_error",
     "dnag_cate_state_floats", "dnag_cate_table_floats", "dnag_cate_packed_floats", "dnag_cate_pack",
     "dnag_pred_state_floats", "dnag_pred_table_floats", "dnag_pred_packed_floats", "dnag_pred_pack",
-    "dnag_workspace_bytes", "dnag_cate_forward", "dnag_pred_forward_grad", "dnag_pc_sample",
+    "dnag_predcate_state_floats", "dnag_predcate_table_floats", "dnag_predcate_packed_floats", "dnag_predcate_pack",
+    "dnag_predcate_workspace_bytes", "dnag_workspace_bytes", "dnag_workspace_bytes_predcate",
+    "dnag_cate_forward", "dnag_pred_forward_grad", "dnag_predcate_forward_grad", "dnag_pc_sample",
     "dnag_quantize", "dnag_timing_begin", "dnag_timing_read", "dnag_timing_end",
 )
 
@@ -39,13 +41,19 @@ class PredDimsC(C.Structure):
                 ("max_node", "n_vocab", "gcn_hidden", "gcn_layers", "linear_hidden", "hs", "nz")]
 
 
+class PredCateDimsC(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("max_node", "n_vocab", "d_model", "n_head", "d_ff", "n_layers", "hs", "nz")]
+
+
 _fp = C.c_void_p   # float* (device or host address)
 
 
 class PcArgsC(C.Structure):
     _fields_ = [
         ("cate_dims", C.POINTER(CateDimsC)), ("cate_packed", _fp),
-        ("pred_dims", C.POINTER(PredDimsC)), ("pred_packed", _fp), ("d_mu", _fp),
+        ("pred_dims", C.POINTER(PredDimsC)), ("pred_packed", _fp),
+        ("predcate_dims", C.POINTER(PredCateDimsC)), ("predcate_packed", _fp), ("d_mu", _fp),
         ("classifier_scale", C.c_float), ("label_sign", C.c_float),
         ("batch", C.c_int32), ("mask", _fp), ("sched", _fp), ("n_steps", C.c_int32),
         ("snr", C.c_float), ("corrector", C.c_int32),
@@ -81,6 +89,17 @@ def load() -> C.CDLL:
     for n in ("dnag_pred_state_floats", "dnag_pred_table_floats", "dnag_pred_packed_floats"):
         getattr(lib, n).restype = sz
         getattr(lib, n).argtypes = [C.POINTER(PredDimsC)]
+    for n in ("dnag_predcate_state_floats", "dnag_predcate_table_floats", "dnag_predcate_packed_floats"):
+        getattr(lib, n).restype = sz
+        getattr(lib, n).argtypes = [C.POINTER(PredCateDimsC)]
+    lib.dnag_predcate_pack.restype = i32
+    lib.dnag_predcate_pack.argtypes = [C.POINTER(PredCateDimsC), vp, vp, vp]
+    lib.dnag_predcate_workspace_bytes.restype = sz
+    lib.dnag_predcate_workspace_bytes.argtypes = [C.POINTER(PredCateDimsC), i32]
+    lib.dnag_workspace_bytes_predcate.restype = sz
+    lib.dnag_workspace_bytes_predcate.argtypes = [C.POINTER(CateDimsC), C.POINTER(PredCateDimsC), i32, i32]
+    lib.dnag_predcate_forward_grad.restype = i32
+    lib.dnag_predcate_forward_grad.argtypes = [C.POINTER(PredCateDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, sz, vp]
     lib.dnag_cate_pack.restype = i32
     lib.dnag_cate_pack.argtypes = [C.POINTER(CateDimsC), vp, vp, vp]
     lib.dnag_pred_pack.restype = i32

@@ -178,3 +178,12 @@ class CATE(PackedModule):
         if return_concat or return_attn0:
             return out, concat, attn0
         return out
+
+
+def __getattr__(name):
+    """``MetaPredictorCATE`` lives in the reference's ``models/cate.py``; here it is defined in
+    ``predictor_cate`` (it needs the shared dataset branch) and re-exported lazily."""
+    if name == "MetaPredictorCATE":
+        from .predictor_cate import MetaPredictorCATE
+        return MetaPredictorCATE
+    raise AttributeError(name)

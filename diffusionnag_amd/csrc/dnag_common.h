@@ -145,6 +145,71 @@ static inline __host__ __device__ PredLayout pred_layout(const dnag_pred_dims &c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel layout of the MetaPredictorCATE surrogate (OFA).  Its embedding, encoder and `final` MLP
+// have the CATE structure (L = 2, H = 2, d_ff = 32, no positional table), so that part is a
+// CateLayout at offset 0.  Behind it:
+//   per encoder layer, fragment-major TRANSPOSED operands of the backward pass
+//     wqkvT [d][3d]  woT [d][d]  w1T [d][dff]  w2T [dff][d]     (dA = dC W  ==  dC (W^T)^T)
+//   f0T [F][Hd], f1T [Hd][Hd]                  final.linears.{0,1} transposed, row-major
+//   r0_w [R2P][RK] r0_b [R2P] r0T [RNP][R2P]   regeress.linears.0, zero padded (R = N V = 180,
+//   r1_w [R2P][R2P] r1_b [R2P] r1T [R2P][R2P]    RK = 192, 2R = 360 -> R2P = 384, RNP = 256)
+//   p0_wd [hs][nz] p0_wa [hs][R2P] p0_b [hs] p0T [R2P][hs]   pred_fc.0 split into dataset | arch
+//   p2_w [hs] p2_b
+// ---------------------------------------------------------------------------------------------
+#define DNAG_MAX_PCL 4
+struct PredCateLayout {
+    CateLayout enc;
+    int hs, nz, R, RK, R2, R2P, RNP;
+    size_t bl[DNAG_MAX_PCL];           // per-layer base of the backward operands
+    size_t b_wqkvT, b_woT, b_w1T, b_w2T;   // relative to bl[l]
+    size_t f0T, f1T;
+    size_t r0_w, r0_b, r0T, r1_w, r1_b, r1T;
+    size_t p0_wd, p0_wa, p0_b, p0T, p2_w, p2_b;
+    size_t total;
+};
+
+static inline __host__ __device__ dnag_cate_dims predcate_as_cate(const dnag_predcate_dims &c) {
+    dnag_cate_dims e;
+    e.max_node = c.max_node; e.n_vocab = c.n_vocab; e.d_model = c.d_model; e.n_head = c.n_head;
+    e.d_ff = c.d_ff; e.n_layers = c.n_layers; e.stagewise_pos = 0;
+    return e;
+}
+
+static inline __host__ __device__ size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static inline __host__ __device__ PredCateLayout predcate_layout(const dnag_predcate_dims &c) {
+    PredCateLayout y;
+    y.enc = cate_layout(predcate_as_cate(c));
+    y.hs = c.hs; y.nz = c.nz;
+    y.R = c.max_node * c.n_vocab; y.RK = (int)round_up(y.R, 32);
+    y.R2 = 2 * y.R; y.R2P = (int)round_up(y.R2, 128); y.RNP = (int)round_up(y.R, 128);
+    const size_t d = y.enc.d, dff = y.enc.dff, F = y.enc.F, Hd = y.enc.Hd, hs = y.hs, nz = y.nz;
+    size_t o = y.enc.total;
+    size_t l = 0;
+    y.b_wqkvT = l; l += frag_floats(d, 3 * d);
+    y.b_woT = l; l += frag_floats(d, d);
+    y.b_w1T = l; l += frag_floats(d, dff);
+    y.b_w2T = l; l += frag_floats(dff, d);
+    for (int i = 0; i < DNAG_MAX_PCL; ++i) { y.bl[i] = o; if (i < y.enc.L) o += l; }
+    y.f0T = o; o += F * Hd;
+    y.f1T = o; o += Hd * Hd;
+    y.r0_w = o; o += (size_t)y.R2P * y.RK;
+    y.r0_b = o; o += y.R2P;
+    y.r0T = o; o += (size_t)y.RNP * y.R2P;
+    y.r1_w = o; o += (size_t)y.R2P * y.R2P;
+    y.r1_b = o; o += y.R2P;
+    y.r1T = o; o += (size_t)y.R2P * y.R2P;
+    y.p0_wd = o; o += align4(hs * nz);
+    y.p0_wa = o; o += hs * y.R2P;
+    y.p0_b = o; o += align4(hs);
+    y.p0T = o; o += (size_t)y.R2P * hs;
+    y.p2_w = o; o += align4(hs);
+    y.p2_b = o; o += 4;
+    y.total = o;
+    return y;
+}
+
+// ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
 #ifdef __HIPCC__

@@ -178,14 +178,24 @@ struct EncGeom {
     static constexpr size_t lds_floats = (size_t)RP * HS + (size_t)RP * QS + (size_t)G * N * N;
 };
 
+// Activations a backward pass needs (SAVE = true: the surrogate's encoder, dnag_predcate.hip.h), row =
+// graph*N + node, `rows` rows per layer slot:
+//   h [L+1][rows][64] residual stream entering layer l (slot L: leaving the last layer),
+//   h1 [L][rows][64] after the attention block, qkv [L][rows][192] projections incl. bias,
+//   f [L][rows][DFF] FFN hidden after relu.
+struct EncSave {
+    float *h, *h1, *qkv, *f;
+    size_t rows;
+};
+
 // x [batch][N][V]; temb [tstride ? batch : 1][64]; mask [mstride ? batch : 1][N][N];
 // concat [rows_pad][L*64] (row = graph*N + node); attn0 [batch][H][N][N] or null.
-template <int N, int V, int G, int H, int DFF, bool WITH_PE>
+template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict__ P, const CateLayout lay,
                                                          const float *__restrict__ x, const float *__restrict__ temb,
                                                          int tstride, const float *__restrict__ mask, int mstride,
                                                          float *__restrict__ concat, float *__restrict__ attn0, int batch,
-                                                         int dbg_skip) {
+                                                         int dbg_skip, const EncSave sv) {
     typedef EncGeom<N, G, DFF> Ge;
     constexpr int R = Ge::R, MT = Ge::MT, RP = Ge::RP, HS = Ge::HS, QS = Ge::QS;
     constexpr int D = DNAG_D, DK = D / H;
@@ -249,10 +259,13 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                 }
             }
             hbuf[r * HS + c] = val;
+            if constexpr (SAVE) if (r < R && g0 + r / N < batch) sv.h[((size_t)g0 * N + r) * D + c] = val;
         }
     }
     __syncthreads();
     if (dbg_skip & 128) return;
+    // row `lr` of this workgroup is a real graph row (SAVE stores skip the padding)
+    auto live = [&](int lr) { return lr < R && g0 + lr / N < batch; };
 
     for (int l = 0; l < L; ++l) {
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
@@ -265,7 +278,11 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     const int col = nt * 32 + r;
                     const float bv = bias[col];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) qkv[(mt * 32 + acc_row(i, h)) * QS + col] = acc[i] + bv;
+                    for (int i = 0; i < 16; ++i) {
+                        const int lr = mt * 32 + acc_row(i, h);
+                        qkv[lr * QS + col] = acc[i] + bv;
+                        if constexpr (SAVE) if (live(lr)) sv.qkv[((size_t)l * sv.rows + (size_t)g0 * N + lr) * (3 * D) + col] = acc[i] + bv;
+                    }
                 });
         }
         constexpr bool PF_ATT = N <= 8;   // larger graphs need the registers for the attention rows
@@ -330,8 +347,11 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     const float bv = bias[col];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float *hp = hbuf + (mt * 32 + acc_row(i, h)) * HS + col;
-                        *hp = (acc[i] + bv) + *hp;
+                        const int lr = mt * 32 + acc_row(i, h);
+                        float *hp = hbuf + lr * HS + col;
+                        const float hv = (acc[i] + bv) + *hp;
+                        *hp = hv;
+                        if constexpr (SAVE) if (live(lr)) sv.h1[((size_t)l * sv.rows + (size_t)g0 * N + lr) * D + col] = hv;
                     }
                 });
         }
@@ -351,7 +371,12 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     const int col = nt * 32 + r;
                     const float bv = bias[col];
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) qkv[(mt * 32 + acc_row(i, h)) * QS + col] = fmaxf(acc[i] + bv, 0.f);
+                    for (int i = 0; i < 16; ++i) {
+                        const int lr = mt * 32 + acc_row(i, h);
+                        const float fv = fmaxf(acc[i] + bv, 0.f);
+                        qkv[lr * QS + col] = fv;
+                        if constexpr (SAVE) if (live(lr)) sv.f[((size_t)l * sv.rows + (size_t)g0 * N + lr) * DFF + col] = fv;
+                    }
                 });
         }
         if (l + 1 < L && ft_qkv >= 0) load_w64(LP + lay.layer_stride + lay.l_wqkv, ft_qkv, bP);   // next layer's first tile
@@ -367,8 +392,11 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     const float bv = bias[col];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        float *hp = hbuf + (mt * 32 + acc_row(i, h)) * HS + col;
-                        *hp = (acc[i] + bv) + *hp;
+                        const int lr = mt * 32 + acc_row(i, h);
+                        float *hp = hbuf + lr * HS + col;
+                        const float hv = (acc[i] + bv) + *hp;
+                        *hp = hv;
+                        if constexpr (SAVE) if (live(lr)) sv.h[((size_t)(l + 1) * sv.rows + (size_t)g0 * N + lr) * D + col] = hv;
                     }
                 });
         }

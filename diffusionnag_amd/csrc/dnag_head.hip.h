@@ -19,11 +19,19 @@
 #define GEMM_NP (GEMM_BM / GEMM_RPP)  // staging passes per operand
 #define GEMM_OCC (GEMM_BK == 16 ? 3 : 2)
 
-// A [M][K] row-major (M % 128 == 0), W [Nout][K] row-major (Nout % 128 == 0), K % 32 == 0.
-template <bool ELU, int TAG>
+// Epilogues of the tile GEMM
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2, ACT_MUL_ELUGRAD = 3 };
+
+// C[M][nvalid] = act(A W^T + bias).  A rows have stride lda (>= K, a multiple of 4), C and aux rows stride
+// ldc; M % 128 == 0, Nout % 128 == 0, K % 32 == 0 (callers zero-pad the weights; only the first nvalid
+// <= Nout columns are stored).  bias may be null.
+// ACT_MUL_ELUGRAD multiplies by elu'(z) given aux = elu(z): 1 for aux > 0, else aux + 1 (backward
+// pass of an ELU layer).  TAG only separates instantiations in profiles.
+template <int ACT, int TAG>
 __global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                                const float *__restrict__ bias, float *__restrict__ C,
-                                                               int M, int Nout, int K) {
+                                                               const float *__restrict__ aux,
+                                                               int M, int Nout, int K, int lda, int ldc, int nvalid) {
     __shared__ __attribute__((aligned(16))) float As[2][GEMM_BM * GEMM_LS];
     __shared__ __attribute__((aligned(16))) float Bs[2][GEMM_BN * GEMM_LS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -39,7 +47,7 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const floa
     const int tm = wg / nbn, tn = wg - tm * nbn;
 
     const int lrow = tid / GEMM_TPR, lk = (tid % GEMM_TPR) * 4;
-    const float *Ag = A + (size_t)(tm * GEMM_BM + lrow) * K + lk;
+    const float *Ag = A + (size_t)(tm * GEMM_BM + lrow) * lda + lk;
     const float *Wg = W + (size_t)(tn * GEMM_BN + lrow) * K + lk;
 
     f32x16 acc[2][2];
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const floa
     auto gload = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < GEMM_NP; ++p) {
-            ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(GEMM_RPP * p) * K + kt * GEMM_BK);
+            ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(GEMM_RPP * p) * lda + kt * GEMM_BK);
             rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(GEMM_RPP * p) * K + kt * GEMM_BK);
         }
     };
@@ -110,15 +118,19 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const floa
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = tn * GEMM_BN + wn * 64 + j * 32 + r;
-        const float bv = bias[col];
+        if (col >= nvalid) continue;
+        const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row0 = tm * GEMM_BM + wm * 64 + i * 32;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
+                const size_t at = (size_t)(row0 + acc_row(e, h)) * ldc + col;
                 float v = acc[i][j][e] + bv;
-                if (ELU) v = v > 0.f ? v : __expf(v) - 1.0f;   // elu: exp(x) - 1 on the hardware exponential
-                C[(size_t)(row0 + acc_row(e, h)) * Nout + col] = v;
+                if (ACT == ACT_ELU) v = v > 0.f ? v : __expf(v) - 1.0f;   // elu: exp(x) - 1 on the hardware exponential
+                if (ACT == ACT_TANH) v = tanhf(v);   // pred_fc.0 of the OFA surrogate (cate.py:348)
+                if (ACT == ACT_MUL_ELUGRAD) { const float a = aux[at]; v *= a > 0.f ? 1.0f : a + 1.0f; }
+                C[at] = v;
             }
         }
     }
@@ -138,6 +150,7 @@ struct ExitArgs {
     const float *cgrad;           // [batch][N][V]
     // EXIT_FORWARD
     float *out;                   // [batch][N][V] raw model output
+    int out_gstride;              // floats between graphs in `out` (0: N*V, contiguous)
     // EXIT_CORRECTOR
     float *gbuf;                  // [batch][N][V] total gradient
     float *partials;              // [2][gridDim.x]: per-block sums of ||grad_b||, ||noise_b||
@@ -214,7 +227,8 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
             const float val = ((red[0][rr][v] + red[1][rr][v]) + (red[2][rr][v] + red[3][rr][v])) + b3[v];
             const size_t e = (size_t)(row0 + rr) * V + v;
             if (a.mode == EXIT_FORWARD) {
-                a.out[e] = val;
+                if (a.out_gstride) a.out[(size_t)(blockIdx.x * GF + g) * a.out_gstride + (rr - g * N) * V + v] = val;
+                else a.out[e] = val;
             } else {
                 const float score = __fdiv_rn(-val, a.std);                       // models/utils.py:103
                 total = score;

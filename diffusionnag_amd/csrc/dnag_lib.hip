@@ -14,6 +14,7 @@
 #include "dnag_encoder.hip.h"
 #include "dnag_head.hip.h"
 #include "dnag_predictor.hip.h"
+#include "dnag_predcate.hip.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -68,6 +69,19 @@ static int check_pred(const dnag_pred_dims *d) {
     return 0;
 }
 
+static int check_predcate(const dnag_predcate_dims *d) {
+    if (!d) return fail(DNAG_E_ARG, "predcate dims is NULL");
+    if (d->max_node != 20 || d->n_vocab != 9)
+        return fail(DNAG_E_ARG, "MetaPredictorCATE kernels are built for 20x9 graphs, got %dx%d", d->max_node, d->n_vocab);
+    if (d->d_model != 64 || d->n_head != 2 || d->d_ff != 32)
+        return fail(DNAG_E_ARG, "unsupported MetaPredictorCATE width: d_model=%d n_head=%d d_ff=%d (built for 64/2/32)",
+                    d->d_model, d->n_head, d->d_ff);
+    if (d->n_layers < 1 || d->n_layers > DNAG_MAX_PCL) return fail(DNAG_E_ARG, "unsupported n_layers=%d", d->n_layers);
+    if (d->hs < GEMM_BN || d->hs % GEMM_BN || d->hs > 4096) return fail(DNAG_E_ARG, "unsupported hs=%d (a multiple of %d)", d->hs, GEMM_BN);
+    if (d->nz < 1 || d->nz > 1024) return fail(DNAG_E_ARG, "unsupported nz=%d", d->nz);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // packing (host only)
 // ---------------------------------------------------------------------------------------------
@@ -85,10 +99,21 @@ extern "C" size_t dnag_cate_table_floats(const dnag_cate_dims *c) {
 }
 extern "C" size_t dnag_cate_packed_floats(const dnag_cate_dims *c) { return c ? cate_layout(*c).total : 0; }
 
-extern "C" int dnag_cate_pack(const dnag_cate_dims *c, const float *s, const float *tables, float *out) {
-    if (int rc = check_cate(c)) return rc;
-    if (!s || !tables || !out) return fail(DNAG_E_ARG, "NULL pointer");
-    const CateLayout y = cate_layout(*c);
+// fold gamma/beta of a LayerNorm into the linear that consumes it: W' = W diag(gamma), b' = b + W beta
+static void fold_ln(const float *W, const float *b, const float *gam, const float *bet, size_t rows, size_t d, float *Wo, float *bo) {
+    for (size_t r = 0; r < rows; ++r) {
+        double acc = b[r];
+        for (size_t k = 0; k < d; ++k) {
+            Wo[r * d + k] = W[r * d + k] * gam[k];
+            acc += (double)W[r * d + k] * (double)bet[k];
+        }
+        if (bo) bo[r] = (float)acc;
+    }
+}
+
+// state_dict order -> CateLayout; `pe` may be NULL (no positional table: zeros)
+static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *pe, const float *freq, float *out) {
+    const CateLayout y = cate_layout(c);
     const size_t d = y.d, V = y.V, dff = y.dff, L = y.L, F = y.F, Hd = y.Hd;
     memset(out, 0, y.total * sizeof(float));
     size_t o = 0;
@@ -96,30 +121,19 @@ extern "C" int dnag_cate_pack(const dnag_cate_dims *c, const float *s, const flo
     take(y.emb_w, d * V); take(y.emb_b, d);
     take(y.t1_w, 4 * d * d); take(y.t1_b, 4 * d);
     take(y.t2_w, 4 * d * d); take(y.t2_b, d);
-    // fold gamma/beta of a LayerNorm into the linear that consumes it: W' = W diag(gamma), b' = b + W beta
-    auto fold = [&](const float *W, const float *b, const float *gam, const float *bet, size_t rows, float *Wo, float *bo) {
-        for (size_t r = 0; r < rows; ++r) {
-            double acc = b[r];
-            for (size_t k = 0; k < d; ++k) {
-                Wo[r * d + k] = W[r * d + k] * gam[k];
-                acc += (double)W[r * d + k] * (double)bet[k];
-            }
-            bo[r] = (float)acc;
-        }
-    };
     std::vector<float> tmp((3 * d > dff ? 3 * d : dff) * d);
     for (size_t l = 0; l < L; ++l) {
         float *LP = out + y.layer0 + l * y.layer_stride;
         const float *ln1g = s + o, *ln1b = s + o + d; o += 2 * d;
         for (int j = 0; j < 3; ++j) {   // Q, K, V
-            fold(s + o, s + o + d * d, ln1g, ln1b, d, tmp.data() + j * d * d, LP + y.l_bqkv + j * d);
+            fold_ln(s + o, s + o + d * d, ln1g, ln1b, d, d, tmp.data() + j * d * d, LP + y.l_bqkv + j * d);
             o += d * d + d;
         }
         frag_pack(tmp.data(), 3 * d, d, d, LP + y.l_wqkv);
         frag_pack(s + o, d, d, d, LP + y.l_wo); o += d * d;
         memcpy(LP + y.l_bo, s + o, d * sizeof(float)); o += d;
         const float *ln2g = s + o, *ln2b = s + o + d; o += 2 * d;
-        fold(s + o, s + o + dff * d, ln2g, ln2b, dff, tmp.data(), LP + y.l_b1); o += dff * d + dff;
+        fold_ln(s + o, s + o + dff * d, ln2g, ln2b, dff, d, tmp.data(), LP + y.l_b1); o += dff * d + dff;
         frag_pack(tmp.data(), dff, d, d, LP + y.l_w1);
         frag_pack(s + o, d, dff, dff, LP + y.l_w2); o += d * dff;
         memcpy(LP + y.l_b2, s + o, d * sizeof(float)); o += d;
@@ -132,10 +146,16 @@ extern "C" int dnag_cate_pack(const dnag_cate_dims *c, const float *s, const flo
     take(y.f0_w, Hd * F); take(y.f0_b, Hd);
     take(y.f1_w, Hd * Hd); take(y.f1_b, Hd);
     take(y.f2_w, V * Hd); take(y.f2_b, V);
-    if (o != dnag_cate_state_floats(c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_cate_state_floats(c));
-    memcpy(out + y.pe, tables, (size_t)y.N * d * sizeof(float));
-    memcpy(out + y.freq, tables + (size_t)y.N * d, (d / 2) * sizeof(float));
+    if (o != dnag_cate_state_floats(&c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_cate_state_floats(&c));
+    if (pe) memcpy(out + y.pe, pe, (size_t)y.N * d * sizeof(float));
+    memcpy(out + y.freq, freq, (d / 2) * sizeof(float));
     return 0;
+}
+
+extern "C" int dnag_cate_pack(const dnag_cate_dims *c, const float *s, const float *tables, float *out) {
+    if (int rc = check_cate(c)) return rc;
+    if (!s || !tables || !out) return fail(DNAG_E_ARG, "NULL pointer");
+    return cate_pack_impl(*c, s, tables, tables + (size_t)c->max_node * c->d_model, out);
 }
 
 extern "C" size_t dnag_pred_state_floats(const dnag_pred_dims *c) {
@@ -192,20 +212,135 @@ extern "C" int dnag_pred_pack(const dnag_pred_dims *c, const float *s, const flo
     return 0;
 }
 
+extern "C" size_t dnag_predcate_state_floats(const dnag_predcate_dims *c) {
+    if (!c) return 0;
+    const dnag_cate_dims e = predcate_as_cate(*c);
+    const size_t R = (size_t)c->max_node * c->n_vocab, hs = c->hs, nz = c->nz;
+    return dnag_cate_state_floats(&e) + (2 * R * R + 2 * R) + (2 * R * 2 * R + 2 * R) + hs * (nz + 2 * R) + hs + hs + 1;
+}
+extern "C" size_t dnag_predcate_table_floats(const dnag_predcate_dims *c) { return c ? (size_t)c->d_model / 2 : 0; }
+extern "C" size_t dnag_predcate_packed_floats(const dnag_predcate_dims *c) { return c ? predcate_layout(*c).total : 0; }
+
+extern "C" int dnag_predcate_pack(const dnag_predcate_dims *c, const float *s, const float *tables, float *out) {
+    if (int rc = check_predcate(c)) return rc;
+    if (!s || !tables || !out) return fail(DNAG_E_ARG, "NULL pointer");
+    const PredCateLayout y = predcate_layout(*c);
+    const dnag_cate_dims e = predcate_as_cate(*c);
+    memset(out, 0, y.total * sizeof(float));
+    if (int rc = cate_pack_impl(e, s, nullptr, tables, out)) return rc;
+    const size_t d = y.enc.d, dff = y.enc.dff, L = y.enc.L, F = y.enc.F, Hd = y.enc.Hd, V = y.enc.V;
+    const size_t R = y.R, RK = y.RK, R2 = y.R2, R2P = y.R2P, hs = y.hs, nz = y.nz;
+    // transposed operands of the encoder's backward pass (second walk over the layer parameters)
+    size_t o = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d;
+    std::vector<float> w((3 * d > dff ? 3 * d : dff) * d), t(3 * d * d);
+    auto transpose = [&](const float *W, size_t rows, size_t cols) {   // W [rows][cols] -> t [cols][rows]
+        for (size_t i = 0; i < rows; ++i)
+            for (size_t k = 0; k < cols; ++k) t[k * rows + i] = W[i * cols + k];
+    };
+    for (size_t l = 0; l < L; ++l) {
+        float *LB = out + y.bl[l];
+        const float *ln1g = s + o, *ln1b = s + o + d; o += 2 * d;
+        for (int j = 0; j < 3; ++j) { fold_ln(s + o, s + o + d * d, ln1g, ln1b, d, d, w.data() + j * d * d, nullptr); o += d * d + d; }
+        transpose(w.data(), 3 * d, d);                      // Wqkv' [3d][d] -> [d][3d]
+        frag_pack(t.data(), d, 3 * d, 3 * d, LB + y.b_wqkvT);
+        transpose(s + o, d, d); o += d * d + d;             // Wo [d][d]
+        frag_pack(t.data(), d, d, d, LB + y.b_woT);
+        const float *ln2g = s + o, *ln2b = s + o + d; o += 2 * d;
+        fold_ln(s + o, s + o + dff * d, ln2g, ln2b, dff, d, w.data(), nullptr); o += dff * d + dff;
+        transpose(w.data(), dff, d);                        // W1' [dff][d] -> [d][dff]
+        frag_pack(t.data(), d, dff, dff, LB + y.b_w1T);
+        transpose(s + o, d, dff); o += d * dff + d;         // W2 [d][dff] -> [dff][d]
+        frag_pack(t.data(), dff, d, d, LB + y.b_w2T);
+    }
+    o += L * 2 * d;
+    for (size_t j = 0; j < Hd; ++j)                          // final.linears.0 [Hd][F] -> [F][Hd]
+        for (size_t k = 0; k < F; ++k) out[y.f0T + k * Hd + j] = s[o + j * F + k];
+    o += Hd * F + Hd;
+    for (size_t j = 0; j < Hd; ++j)                          // final.linears.1 [Hd][Hd] -> transposed
+        for (size_t k = 0; k < Hd; ++k) out[y.f1T + k * Hd + j] = s[o + j * Hd + k];
+    o += Hd * Hd + Hd;
+    o += V * Hd + V;
+    if (o != dnag_cate_state_floats(&e)) return fail(DNAG_E_ARG, "internal: encoder walk consumed %zu of %zu floats", o, dnag_cate_state_floats(&e));
+    for (size_t j = 0; j < R2; ++j)                          // regeress.linears.0 [2R][R]
+        for (size_t k = 0; k < R; ++k) {
+            out[y.r0_w + j * RK + k] = s[o + j * R + k];
+            out[y.r0T + k * R2P + j] = s[o + j * R + k];
+        }
+    o += R2 * R;
+    memcpy(out + y.r0_b, s + o, R2 * sizeof(float)); o += R2;
+    for (size_t j = 0; j < R2; ++j)                          // regeress.linears.1 [2R][2R]
+        for (size_t k = 0; k < R2; ++k) {
+            out[y.r1_w + j * R2P + k] = s[o + j * R2 + k];
+            out[y.r1T + k * R2P + j] = s[o + j * R2 + k];
+        }
+    o += R2 * R2;
+    memcpy(out + y.r1_b, s + o, R2 * sizeof(float)); o += R2;
+    for (size_t j = 0; j < hs; ++j) {                        // pred_fc.0 [hs][nz + 2R]
+        const float *row = s + o + j * (nz + R2);
+        memcpy(out + y.p0_wd + j * nz, row, nz * sizeof(float));
+        for (size_t k = 0; k < R2; ++k) {
+            out[y.p0_wa + j * R2P + k] = row[nz + k];
+            out[y.p0T + k * hs + j] = row[nz + k];
+        }
+    }
+    o += hs * (nz + R2);
+    memcpy(out + y.p0_b, s + o, hs * sizeof(float)); o += hs;
+    memcpy(out + y.p2_w, s + o, hs * sizeof(float)); o += hs;
+    out[y.p2_b] = s[o]; o += 1;
+    if (o != dnag_predcate_state_floats(c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_predcate_state_floats(c));
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
     size_t rows, rows_pad;
-    size_t labels, temb_s, temb_p, concat, h1, h2, cgrad, gbuf, x, x_mean, partials, total;   // float offsets
+    size_t labels, temb_s, temb_p, concat, h1, h2, cgrad, gbuf, x, x_mean, partials, pc, total;   // float offsets
     int nblk_exit;
+};
+
+// workspace of one MetaPredictorCATE evaluation (float offsets relative to its base)
+struct PcWs {
+    size_t rows, rows_pad, bpad;
+    size_t beff, concat, h1, h2, flat, r1, r2, pz, dr2, dr1, dflat, dh1, dconcat, sv_h, sv_h1, sv_qkv, sv_f, total;
 };
 
 static size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static int exit_gf(const dnag_cate_dims &c) { return is_nb201(c) ? 8 : 3; }
 
-static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int batch, int n_steps) {
+static PcWs predcate_ws(const PredCateLayout &y, int batch) {
+    PcWs w;
+    const size_t N = y.enc.N, d = y.enc.d, F = y.enc.F, Hd = y.enc.Hd, L = y.enc.L;
+    w.rows = (size_t)batch * N;
+    w.rows_pad = up(w.rows, GEMM_BM);
+    w.bpad = up((size_t)batch, GEMM_BM);
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += up(n, 64); return at; };
+    w.beff = take(y.hs);
+    w.concat = take(w.rows_pad * F);
+    w.h1 = take(w.rows_pad * Hd);
+    w.h2 = take(w.rows_pad * Hd);
+    w.flat = take(w.bpad * y.RK);
+    w.r1 = take(w.bpad * y.R2P);
+    w.r2 = take(w.bpad * y.R2P);
+    w.pz = take(w.bpad * y.hs);
+    w.dr2 = take(w.bpad * y.R2P);
+    w.dr1 = take(w.bpad * y.R2P);
+    w.dflat = take(w.bpad * y.RK);
+    w.dh1 = take(w.rows_pad * Hd);
+    w.dconcat = take(w.rows_pad * F);
+    w.sv_h = take((L + 1) * w.rows_pad * d);
+    w.sv_h1 = take(L * w.rows_pad * d);
+    w.sv_qkv = take(L * w.rows_pad * 3 * d);
+    w.sv_f = take(L * w.rows_pad * y.enc.dff);
+    w.total = o;
+    return w;
+}
+
+static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int batch, int n_steps,
+                          const dnag_predcate_dims *pc = nullptr) {
     WsLayout w;
     const size_t N = c.max_node, V = c.n_vocab, F = (size_t)c.n_layers * c.d_model, Hd = 2 * F;
     const size_t nt = (size_t)(n_steps > batch ? n_steps : batch);
@@ -216,7 +351,7 @@ static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int 
     auto take = [&](size_t n) { size_t at = o; o += up(n, 64); return at; };
     w.labels = take(nt);
     w.temb_s = take(nt * c.d_model);
-    w.temb_p = take(p ? nt * p->gcn_hidden : 0);
+    w.temb_p = take(p ? nt * p->gcn_hidden : pc ? nt * pc->d_model : 0);
     w.concat = take(w.rows_pad * F);
     w.h1 = take(w.rows_pad * Hd);
     w.h2 = take(w.rows_pad * Hd);
@@ -225,6 +360,8 @@ static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int 
     w.x = take((size_t)batch * N * V);
     w.x_mean = take((size_t)batch * N * V);
     w.partials = take(2 * (size_t)w.nblk_exit);
+    w.pc = o;
+    if (pc) o += predcate_ws(predcate_layout(*pc), batch).total;
     w.total = o;
     return w;
 }
@@ -232,6 +369,14 @@ static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int 
 extern "C" size_t dnag_workspace_bytes(const dnag_cate_dims *cd, const dnag_pred_dims *pd, int batch, int n_steps) {
     if (!cd || batch < 1) return 0;
     return ws_layout(*cd, pd, batch, n_steps < 1 ? 1 : n_steps).total * sizeof(float);
+}
+extern "C" size_t dnag_workspace_bytes_predcate(const dnag_cate_dims *cd, const dnag_predcate_dims *pd, int batch, int n_steps) {
+    if (!cd || batch < 1) return 0;
+    return ws_layout(*cd, nullptr, batch, n_steps < 1 ? 1 : n_steps, pd).total * sizeof(float);
+}
+extern "C" size_t dnag_predcate_workspace_bytes(const dnag_predcate_dims *d, int batch) {
+    if (!d || batch < 1) return 0;
+    return (up((size_t)batch * d->d_model, 64) + predcate_ws(predcate_layout(*d), batch).total) * sizeof(float);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -287,10 +432,20 @@ static int env_int(const char *name) { const char *v = getenv(name); return v ? 
 // ---------------------------------------------------------------------------------------------
 #define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
 
+// C = act(A W^T + bias); `timed` marks the launches bench.py's roofline is computed on (final.linears.1)
+template <int ACT, int TAG>
+static int launch_gemm_t(const float *A, const float *W, const float *bias, float *C, const float *aux, size_t M, int Nout, int K,
+                         int lda, int ldc, int nvalid, hipStream_t st) {
+    if (M % GEMM_BM || Nout % GEMM_BN || K % GEMM_BK || lda % 4 || nvalid > Nout || nvalid > ldc)
+        return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d (lda %d ldc %d nvalid %d) not tile aligned", M, Nout, K, lda, ldc, nvalid);
+    const int grid = (int)(M / GEMM_BM) * (Nout / GEMM_BN);
+    hipLaunchKernelGGL((gemm_bias_act_kernel<ACT, TAG>), dim3(grid), dim3(256), 0, st, A, W, bias, C, aux, (int)M, Nout, K, lda, ldc, nvalid);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 static int launch_gemm(const float *A, const float *W, const float *bias, float *C, size_t M, int Nout, int K, bool timed,
                        size_t real_rows, hipStream_t st) {
-    if (M % GEMM_BM || Nout % GEMM_BN || K % GEMM_BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
-    const int grid = (int)(M / GEMM_BM) * (Nout / GEMM_BN);
     int slot = -1;
     if (timed) {
         std::lock_guard<std::mutex> lk(g_tm_mu);
@@ -302,11 +457,9 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev0[slot], st));
     // two instantiations so that profiles list final.linears.0 (K = F) and final.linears.1 (K = 2F) apart
-    if (timed)
-        hipLaunchKernelGGL((gemm_bias_act_kernel<true, 1>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
-    else
-        hipLaunchKernelGGL((gemm_bias_act_kernel<true, 0>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
-    LAUNCH_CHECK();
+    int rc = timed ? launch_gemm_t<ACT_ELU, 1>(A, W, bias, C, nullptr, M, Nout, K, K, Nout, Nout, st)
+                   : launch_gemm_t<ACT_ELU, 0>(A, W, bias, C, nullptr, M, Nout, K, K, Nout, Nout, st);
+    if (rc) return rc;
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
     return 0;
 }
@@ -331,7 +484,9 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
         attr_set = true;
     }
     const int grid = (batch + G - 1) / G;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch, env_int("DNAG_ENC_SKIP"));
+    EncSave none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch, env_int("DNAG_ENC_SKIP"), none);
     LAUNCH_CHECK();
     return 0;
 }
@@ -421,13 +576,121 @@ extern "C" int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *pack
 }
 
 // ---------------------------------------------------------------------------------------------
+// MetaPredictorCATE (OFA surrogate): forward and input gradient as a sequence of launches
+// ---------------------------------------------------------------------------------------------
+#define PC_N 20
+#define PC_V 9
+#define PC_G 3
+
+// once per call: c0 = b0 + W0[:, :nz] D_mu, and the zero K-padding of the flattened activations
+static int predcate_prepare(const PredCateLayout &y, const float *P, const float *d_mu, float *ws, const PcWs &w, hipStream_t st) {
+    hipLaunchKernelGGL(predfc0_bias_kernel, dim3((y.hs + 255) / 256), dim3(256), 0, st, P + y.p0_wd, P + y.p0_b, d_mu, y.hs, y.nz,
+                       ws + w.beff);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemsetAsync(ws + w.flat, 0, w.bpad * y.RK * sizeof(float), st));
+    return 0;
+}
+
+// x [batch][20][9] -> y [batch] (or null), grad [batch][20][9] (or null); temb rows of 64
+static int run_predcate(const PredCateLayout &y, const float *P, const float *x, const float *temb, int tstride, const float *mask,
+                        int mstride, float *yout, float *grad, int batch, float *ws, const PcWs &w, hipStream_t st) {
+    const CateLayout &e = y.enc;
+    const int F = e.F, Hd = e.Hd;
+    EncSave sv;
+    sv.h = ws + w.sv_h; sv.h1 = ws + w.sv_h1; sv.qkv = ws + w.sv_qkv; sv.f = ws + w.sv_f; sv.rows = w.rows_pad;
+    {   // encoder, saving what the backward pass needs
+        typedef EncGeom<PC_N, PC_G, 32> Ge;
+        const size_t lds = Ge::lds_floats * sizeof(float);
+        auto kern = encoder_kernel<PC_N, PC_V, PC_G, 2, 32, false, true>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((batch + PC_G - 1) / PC_G), dim3(256), lds, st, P, e, x, temb, tstride, mask, mstride,
+                           ws + w.concat, (float *)nullptr, batch, 0, sv);
+        LAUNCH_CHECK();
+    }
+    // final MLP (cate.py:323), flatten, regeress MLP (:325-326), pred_fc (:348)
+    if (int rc = launch_gemm_t<ACT_ELU, 2>(ws + w.concat, P + e.f0_w, P + e.f0_b, ws + w.h1, nullptr, w.rows_pad, Hd, F, F, Hd, Hd, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_ELU, 2>(ws + w.h1, P + e.f1_w, P + e.f1_b, ws + w.h2, nullptr, w.rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    {
+        ExitArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = EXIT_FORWARD; a.batch = batch; a.out = ws + w.flat; a.out_gstride = y.RK;
+        hipLaunchKernelGGL((head_out_kernel<PC_N, PC_V, PC_G>), dim3((batch + PC_G - 1) / PC_G), dim3(256), 0, st, ws + w.h2, P + e.f2_w,
+                           P + e.f2_b, Hd, a);
+        LAUNCH_CHECK();
+    }
+    if (int rc = launch_gemm_t<ACT_ELU, 2>(ws + w.flat, P + y.r0_w, P + y.r0_b, ws + w.r1, nullptr, w.bpad, y.R2P, y.RK, y.RK, y.R2P, y.R2P, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_NONE, 2>(ws + w.r1, P + y.r1_w, P + y.r1_b, ws + w.r2, nullptr, w.bpad, y.R2P, y.R2P, y.R2P, y.R2P, y.R2P, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_TANH, 2>(ws + w.r2, P + y.p0_wa, ws + w.beff, ws + w.pz, nullptr, w.bpad, y.hs, y.R2P, y.R2P, y.hs, y.hs, st)) return rc;
+    hipLaunchKernelGGL(predfc2_kernel, dim3(batch), dim3(256), 0, st, ws + w.pz, y.hs, P + y.p2_w, P + y.p2_b, yout, grad ? 1 : 0);
+    LAUNCH_CHECK();
+    if (!grad) return 0;
+    // backward: transposed weights, elu' from the stored activations
+    if (int rc = launch_gemm_t<ACT_NONE, 2>(ws + w.pz, P + y.p0T, nullptr, ws + w.dr2, nullptr, w.bpad, y.R2P, y.hs, y.hs, y.R2P, y.R2P, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_MUL_ELUGRAD, 2>(ws + w.dr2, P + y.r1T, nullptr, ws + w.dr1, ws + w.r1, w.bpad, y.R2P, y.R2P, y.R2P, y.R2P, y.R2P, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_NONE, 2>(ws + w.dr1, P + y.r0T, nullptr, ws + w.dflat, nullptr, w.bpad, y.RNP, y.R2P, y.R2P, y.RK, y.RK, st)) return rc;
+    {
+        const size_t rows = w.rows;
+        const int grid = (int)(rows < 4096 ? rows : 4096);
+        hipLaunchKernelGGL((final2_bwd_kernel<PC_N, PC_V>), dim3(grid), dim3(256), 0, st, ws + w.h2, ws + w.dflat, y.RK, P + e.f2_w, Hd, rows);
+        LAUNCH_CHECK();
+    }
+    if (int rc = launch_gemm_t<ACT_MUL_ELUGRAD, 2>(ws + w.h2, P + y.f1T, nullptr, ws + w.dh1, ws + w.h1, w.rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_NONE, 2>(ws + w.dh1, P + y.f0T, nullptr, ws + w.dconcat, nullptr, w.rows_pad, F, Hd, Hd, F, F, st)) return rc;
+    {
+        typedef PcbGeom<PC_N, PC_G, 2, 32> Ge;
+        const size_t lds = Ge::lds_floats * sizeof(float);
+        auto kern = predcate_enc_bwd_kernel<PC_N, PC_V, PC_G, 2, 32>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((batch + PC_G - 1) / PC_G), dim3(256), lds, st, P, y, sv, ws + w.dconcat, mask, mstride, grad, batch);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int dnag_predcate_forward_grad(const dnag_predcate_dims *d, const float *packed, const float *x, const float *time_cond,
+                                          int time_stride, const float *mask, int mask_stride, const float *d_mu, float *y,
+                                          float *grad, int batch, void *workspace, size_t workspace_bytes, void *stream) {
+    if (int rc = check_predcate(d)) return rc;
+    if (!packed || !x || !time_cond || !mask || !d_mu || !workspace) return fail(DNAG_E_ARG, "NULL pointer");
+    if (batch < 1) return fail(DNAG_E_ARG, "batch=%d", batch);
+    const PredCateLayout lay = predcate_layout(*d);
+    const PcWs w = predcate_ws(lay, batch);
+    const size_t nt = time_stride ? batch : 1;
+    const size_t temb_floats = up((size_t)batch * lay.enc.d, 64);
+    if (workspace_bytes < (temb_floats + w.total) * sizeof(float))
+        return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, (temb_floats + w.total) * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float *temb = (float *)workspace, *ws = temb + temb_floats;
+    const CateLayout &e = lay.enc;
+    if (int rc = launch_time_embed(time_cond, (int)nt, e.d, packed, e.freq, e.t1_w, e.t1_b, e.t2_w, e.t2_b, temb, st)) return rc;
+    if (int rc = predcate_prepare(lay, packed, d_mu, ws, w, st)) return rc;
+    return run_predcate(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, y, grad, batch, ws, w, st);
+}
+
+// ---------------------------------------------------------------------------------------------
 // predictor-corrector loop
 // ---------------------------------------------------------------------------------------------
 extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     if (!p) return fail(DNAG_E_ARG, "args is NULL");
     if (int rc = check_cate(p->cate_dims)) return rc;
-    const bool guided = p->pred_dims != nullptr;
-    if (guided) {
+    const bool guided_pc = p->predcate_dims != nullptr;
+    const bool guided = p->pred_dims != nullptr || guided_pc;
+    if (p->pred_dims && guided_pc) return fail(DNAG_E_ARG, "pred_dims and predcate_dims are both set: pass one surrogate");
+    if (guided_pc) {
+        if (int rc = check_predcate(p->predcate_dims)) return rc;
+        if (!p->predcate_packed || !p->d_mu) return fail(DNAG_E_ARG, "guided sampling needs predcate_packed and d_mu");
+        if (p->predcate_dims->max_node != p->cate_dims->max_node || p->predcate_dims->n_vocab != p->cate_dims->n_vocab)
+            return fail(DNAG_E_ARG, "score net and surrogate disagree on the graph shape");
+        if (!(p->label_sign == 1.0f || p->label_sign == -1.0f)) return fail(DNAG_E_ARG, "label_sign must be +1 or -1");
+    } else if (guided) {
         if (int rc = check_pred(p->pred_dims)) return rc;
         if (!p->pred_packed || !p->d_mu) return fail(DNAG_E_ARG, "guided sampling needs pred_packed and d_mu");
         if (p->pred_dims->max_node != p->cate_dims->max_node || p->pred_dims->n_vocab != p->cate_dims->n_vocab)
@@ -440,7 +703,7 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
         return fail(DNAG_E_ARG, "noise_corr and noise_pred must both be given (tape mode) or both NULL (Philox)");
     const dnag_cate_dims &cd = *p->cate_dims;
     const CateLayout lay = cate_layout(cd);
-    const WsLayout w = ws_layout(cd, p->pred_dims, p->batch, p->n_steps);
+    const WsLayout w = ws_layout(cd, p->pred_dims, p->batch, p->n_steps, p->predcate_dims);
     if (p->workspace_bytes < w.total * sizeof(float))
         return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", p->workspace_bytes, w.total * sizeof(float));
     hipStream_t st = (hipStream_t)p->stream;
@@ -448,7 +711,10 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     const int B = p->batch, S = p->n_steps;
     const size_t nelem = (size_t)B * cd.max_node * cd.n_vocab;
     PredLayout play;
-    if (guided) play = pred_layout(*p->pred_dims);
+    PredCateLayout pclay;
+    PcWs pcw;
+    if (guided_pc) { pclay = predcate_layout(*p->predcate_dims); pcw = predcate_ws(pclay, B); }
+    else if (guided) play = pred_layout(*p->pred_dims);
 
     // labels -> device, time embeddings of every step in one launch per network
     std::vector<float> labels(S);
@@ -460,8 +726,13 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     HIP_TRY(hipMemcpyAsync(ws + w.labels, labels.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));   // `labels` is pageable host memory that dies with this call
     if (int rc = launch_time_embed(ws + w.labels, S, lay.d, p->cate_packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, ws + w.temb_s, st)) return rc;
-    if (guided)
+    if (guided_pc) {
+        const CateLayout &e = pclay.enc;
+        if (int rc = launch_time_embed(ws + w.labels, S, e.d, p->predcate_packed, e.freq, e.t1_w, e.t1_b, e.t2_w, e.t2_b, ws + w.temb_p, st)) return rc;
+        if (int rc = predcate_prepare(pclay, p->predcate_packed, p->d_mu, ws + w.pc, pcw, st)) return rc;
+    } else if (guided) {
         if (int rc = launch_time_embed(ws + w.labels, S, play.g, p->pred_packed, play.freq, play.t1_w, play.t1_b, play.t2_w, play.t2_b, ws + w.temb_p, st)) return rc;
+    }
 
     float *x = ws + w.x, *x_mean = ws + w.x_mean, *cgrad = ws + w.cgrad, *gbuf = ws + w.gbuf, *partials = ws + w.partials;
     hipLaunchKernelGGL(prior_kernel, dim3(1024), dim3(256), 0, st, x, p->x0, nelem, p->seed, p->stream_offset);
@@ -474,7 +745,9 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
         for (int phase = p->corrector ? 0 : 1; phase < 2; ++phase) {
             const bool corr = phase == 0;
             if (guided) {
-                if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, p->d_mu, nullptr, cgrad, B, st)) return rc;
+                if (guided_pc) {
+                    if (int rc = run_predcate(pclay, p->predcate_packed, x, ws + w.temb_p + (size_t)i * pclay.enc.d, 0, p->mask, 0, nullptr, cgrad, B, ws + w.pc, pcw, st)) return rc;
+                } else if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, p->d_mu, nullptr, cgrad, B, st)) return rc;
                 float *rc_ = rec_at(corr ? p->rec_cgrad_c : p->rec_cgrad_p, i);
                 if (rc_) HIP_TRY(hipMemcpyAsync(rc_, cgrad, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
             }

@@ -48,8 +48,46 @@ def _setpool(m, X, heads):
     return _linear(getattr(dec, "1"), h)
 
 
+class DatasetBranch:
+    """Dataset branch shared by both surrogates (``digcn_meta.py:131-139`` = ``cate.py:330-338``) and the
+    ``sample_state`` / ``D_mu`` cache of their ``forward`` (``digcn_meta.py:150-156``, ``cate.py:351-357``).
+    Needs ``self.dims.set_heads``, ``self.num_sample``, ``self.intra_setpool``, ``self.inter_setpool``."""
+
+    def set_encode(self, task):
+        """``task`` is ``[B, num_class*num_sample, 512]``; the reference encodes every (identical) row of
+        the batch, one encoding of each distinct row is enough, so rows are encoded one by one only when
+        they differ."""
+        heads = self.dims.set_heads
+        if task.dim() == 2:
+            task = task.unsqueeze(0)
+        first = task[0]
+        same = task.shape[0] == 1 or bool((task == first.unsqueeze(0)).all())
+        rows = [first] if same else list(task)
+        out = []
+        for x in rows:
+            cls_protos = _setpool(self.intra_setpool, x.view(-1, self.num_sample, 512), heads).squeeze(1)
+            out.append(_setpool(self.inter_setpool, cls_protos.unsqueeze(0), heads).reshape(-1))
+        v = torch.stack(out)
+        return v.expand(task.shape[0], -1) if same else v
+
+    def _dataset_embedding(self, task, dev) -> torch.Tensor:
+        """One ``[nz]`` dataset embedding for the whole batch, cached like ``digcn_meta.py:151-155``."""
+        if self.sample_state and self.D_mu is not None:
+            D = self.D_mu
+        else:
+            with torch.no_grad():
+                D = self.set_encode(task)
+            if self.sample_state:
+                self.D_mu = D
+        if D.dim() == 2:
+            if D.shape[0] > 1 and not bool((D == D[:1]).all()):
+                raise NotImplementedError("per-graph dataset embeddings (different tasks inside one batch) are not built")
+            D = D[0]
+        return D.detach().to(dev, torch.float32).contiguous()
+
+
 @mutils.register_model(name='MetaNeuralPredictor')
-class MetaNeuralPredictor(PackedModule):
+class MetaNeuralPredictor(DatasetBranch, PackedModule):
     """Drop-in for the reference's ``MetaeuralPredictor`` [sic] (``digcn_meta.py:56-159``): same
     constructor argument, ``state_dict``, ``forward(X, time_cond, maskX, task)`` and the
     ``sample_state`` / ``D_mu`` caching attributes the sampler toggles (``sampling.py:561-562``)."""
@@ -70,24 +108,6 @@ class MetaNeuralPredictor(PackedModule):
         self.sample_state = False
         self.D_mu = None
         self._ws = Workspace()
-
-    # -- dataset branch (PyTorch, once per call) ------------------------------------------------------
-    def set_encode(self, task):
-        """Reference ``digcn_meta.py:131-139``.  ``task`` is ``[B, num_class*num_sample, 512]``; the
-        reference encodes every (identical) row of the batch, one encoding of each distinct row is
-        enough, so rows are encoded one by one only when they differ."""
-        heads = self.dims.set_heads
-        if task.dim() == 2:
-            task = task.unsqueeze(0)
-        first = task[0]
-        same = task.shape[0] == 1 or bool((task == first.unsqueeze(0)).all())
-        rows = [first] if same else list(task)
-        out = []
-        for x in rows:
-            cls_protos = _setpool(self.intra_setpool, x.view(-1, self.num_sample, 512), heads).squeeze(1)
-            out.append(_setpool(self.inter_setpool, cls_protos.unsqueeze(0), heads).reshape(-1))
-        v = torch.stack(out)
-        return v.expand(task.shape[0], -1) if same else v
 
     # -- packing ---------------------------------------------------------------------------------
     def dims_c(self) -> _lib.PredDimsC:
@@ -114,21 +134,6 @@ class MetaNeuralPredictor(PackedModule):
         return out
 
     # -- HIP calls -----------------------------------------------------------------------------------
-    def _dataset_embedding(self, task, dev) -> torch.Tensor:
-        """One ``[nz]`` dataset embedding for the whole batch, cached like ``digcn_meta.py:151-155``."""
-        if self.sample_state and self.D_mu is not None:
-            D = self.D_mu
-        else:
-            with torch.no_grad():
-                D = self.set_encode(task)
-            if self.sample_state:
-                self.D_mu = D
-        if D.dim() == 2:
-            if D.shape[0] > 1 and not bool((D == D[:1]).all()):
-                raise NotImplementedError("per-graph dataset embeddings (different tasks inside one batch) are not built")
-            D = D[0]
-        return D.detach().to(dev, torch.float32).contiguous()
-
     def _run(self, X, time_cond, maskX, task, want_y, want_grad):
         if self.training:
             raise NotImplementedError("MetaNeuralPredictor on the HIP path is eval-only")

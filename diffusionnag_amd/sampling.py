@@ -15,6 +15,7 @@ import torch
 from . import _lib, sde_lib
 from .cate import CATE, Workspace
 from .digcn_meta import MetaNeuralPredictor
+from .predictor_cate import MetaPredictorCATE
 from .utils import MetaTestDataset
 
 DATA_PATH = "./data/transfer_nag"      # reference all_path.py
@@ -169,8 +170,8 @@ class _PCSampler:
         args.cate_packed = _lib.ptr(score_model.packed(dev))
         pd = None
         if classifier is not None:
-            if not isinstance(classifier, MetaNeuralPredictor):
-                raise TypeError("classifier must be diffusionnag_amd.digcn_meta.MetaNeuralPredictor")
+            if not isinstance(classifier, (MetaNeuralPredictor, MetaPredictorCATE)):
+                raise TypeError("classifier must be diffusionnag_amd's MetaNeuralPredictor or MetaPredictorCATE")
             if classifier_scale is None:
                 raise ValueError("classifier_scale is required for guided sampling")
             classifier.eval()
@@ -178,8 +179,12 @@ class _PCSampler:
             classifier.D_mu = None
             d_mu = classifier._dataset_embedding(task.to(dev), dev)
             pd = classifier.dims_c()
-            args.pred_dims = C.pointer(pd)
-            args.pred_packed = _lib.ptr(classifier.packed(dev))
+            if isinstance(classifier, MetaPredictorCATE):
+                args.predcate_dims = C.pointer(pd)
+                args.predcate_packed = _lib.ptr(classifier.packed(dev))
+            else:
+                args.pred_dims = C.pointer(pd)
+                args.pred_packed = _lib.ptr(classifier.packed(dev))
             args.d_mu = _lib.ptr(d_mu)
             args.classifier_scale = float(classifier_scale)
             args.label_sign = 1.0 if labels == 'max' else -1.0
@@ -233,7 +238,10 @@ class _PCSampler:
             rec["rec_step_size"] = torch.zeros(S, 3, dtype=torch.float32, device=dev)
             for n, t in rec.items():
                 setattr(args, n, _lib.ptr(t))
-        nbytes = lib.dnag_workspace_bytes(C.byref(cd), C.byref(pd) if pd is not None else None, B, S)
+        if isinstance(classifier, MetaPredictorCATE):
+            nbytes = lib.dnag_workspace_bytes_predcate(C.byref(cd), C.byref(pd), B, S)
+        else:
+            nbytes = lib.dnag_workspace_bytes(C.byref(cd), C.byref(pd) if pd is not None else None, B, S)
         ws = self._ws.get(nbytes, dev)
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         args.stream = _lib.current_stream(dev)

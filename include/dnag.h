@@ -46,6 +46,19 @@ typedef struct dnag_pred_dims {
     int32_t nz;            /* 56 */
 } dnag_pred_dims;
 
+/* OFA surrogate shape (MetaPredictorCATE, models/cate.py:251-305; values:
+ * MobileNetV3/configs/tr_meta_surrogate_ofa.py:112-145). */
+typedef struct dnag_predcate_dims {
+    int32_t max_node;      /* 20 */
+    int32_t n_vocab;       /* 9 */
+    int32_t d_model;       /* 64 */
+    int32_t n_head;        /* 2 */
+    int32_t d_ff;          /* 32 */
+    int32_t n_layers;      /* 2 */
+    int32_t hs;            /* 512 */
+    int32_t nz;            /* 56 */
+} dnag_predcate_dims;
+
 int         dnag_abi_version(void);
 const char *dnag_last_error(void);
 
@@ -72,8 +85,19 @@ size_t dnag_pred_table_floats(const dnag_pred_dims *d);
 size_t dnag_pred_packed_floats(const dnag_pred_dims *d);
 int    dnag_pred_pack(const dnag_pred_dims *d, const float *state_flat, const float *tables, float *packed);
 
+/* MetaPredictorCATE: the parameters used while sampling, in state_dict order: opEmb.fc, timeEmb1,
+ * timeEmb2, graph_encoder.* (layers then norms), final.linears.{0,1,2}, regeress.linears.{0,1},
+ * pred_fc.0, pred_fc.2 (weight then bias each).  `tables` = timestep frequencies [d_model/2]. */
+size_t dnag_predcate_state_floats(const dnag_predcate_dims *d);
+size_t dnag_predcate_table_floats(const dnag_predcate_dims *d);
+size_t dnag_predcate_packed_floats(const dnag_predcate_dims *d);
+int    dnag_predcate_pack(const dnag_predcate_dims *d, const float *state_flat, const float *tables, float *packed);
+size_t dnag_predcate_workspace_bytes(const dnag_predcate_dims *d, int batch);
+
 /* Bytes of device workspace needed for a batch of `batch` graphs (`pd` may be NULL). */
 size_t dnag_workspace_bytes(const dnag_cate_dims *cd, const dnag_pred_dims *pd, int batch, int n_steps);
+/* as above for guided sampling with the OFA surrogate */
+size_t dnag_workspace_bytes_predcate(const dnag_cate_dims *cd, const dnag_predcate_dims *pd, int batch, int n_steps);
 
 /* ---- score network forward ------------------------------------------------------------------
  * Replaces CATE.forward(X, time_cond, maskX) (models/cate.py:145-164, eval mode).
@@ -95,6 +119,13 @@ int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *packed, const f
                            const float *time_cond, int time_stride, const float *mask, int mask_stride,
                            const float *d_mu, float *y, float *grad, int batch,
                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same for the OFA surrogate: replaces MetaPredictorCATE.forward with cached D_mu
+ * (models/cate.py:311-360) and get_classifier_grad_fn (models/utils.py:126-147). */
+int dnag_predcate_forward_grad(const dnag_predcate_dims *d, const float *packed, const float *x,
+                               const float *time_cond, int time_stride, const float *mask, int mask_stride,
+                               const float *d_mu, float *y, float *grad, int batch,
+                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- predictor-corrector sampler -------------------------------------------------------------
  * Replaces the loops of pc_sampler (sampling.py:424-445) and pc_conditional_sampler
@@ -118,6 +149,8 @@ typedef struct dnag_pc_args {
     const float *cate_packed;          /* device */
     const dnag_pred_dims *pred_dims;   /* NULL: unconditional */
     const float *pred_packed;          /* device, or NULL */
+    const dnag_predcate_dims *predcate_dims;   /* OFA surrogate instead of pred_dims (at most one of the two) */
+    const float *predcate_packed;      /* device, or NULL */
     const float *d_mu;                 /* device [nz], or NULL */
     float classifier_scale;            /* sampling.py:505 */
     float label_sign;                  /* +1 for labels='max', -1 for 'min' (models/utils.py:136-139) */

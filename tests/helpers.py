@@ -34,5 +34,13 @@ def predictor_config(d, device):
                          num_sample=d.num_sample, graph_encoder=ge))
 
 
+def predictor_cate_config(d, device):
+    ge = Cfg(n_layers=d.n_layers, d_model=d.d_model, n_head=d.n_head, d_ff=d.d_ff, dropout=0.1, n_vocab=d.n_vocab)
+    return Cfg(device=torch.device(device),
+               data=Cfg(name="ofa", max_node=d.max_node, n_vocab=d.n_vocab, centered=True),
+               model=Cfg(name="MetaPredictorCATE", nonlinearity="swish", dropout=0.1, input_type="DA", hs=d.hs, nz=d.nz,
+                         num_sample=d.num_sample, graph_encoder=ge))
+
+
 def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))

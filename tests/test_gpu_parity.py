@@ -10,10 +10,10 @@ import numpy as np
 import pytest
 import torch
 
-from diffusionnag_amd import cate as _cate, digcn_meta as _dm  # noqa: F401  (register the models)
+from diffusionnag_amd import cate as _cate, digcn_meta as _dm, predictor_cate as _pc  # noqa: F401  (register the models)
 from diffusionnag_amd import mutils, sampling, sde_lib, synthetic, utils
-from diffusionnag_amd.specs import CateDims, PredictorDims
-from tests.helpers import golden, predictor_config, score_config
+from diffusionnag_amd.specs import CateDims, PredictorCateDims, PredictorDims
+from tests.helpers import golden, predictor_cate_config, predictor_config, score_config
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -312,3 +312,132 @@ def test_quantize_device_threshold():
     q = utils.quantize(x)
     assert len(q) == 1 and q[0].shape == (8, 7)
     assert np.array_equal(q[0][0], np.array([1, 0, 0, 1, 0, 1, 0], np.float32))
+
+
+# ------------------------------------------------------------------------------------------------
+# OFA (20 x 9): MetaPredictorCATE surrogate and the guided sampler (BASELINE config 4 shapes)
+# ------------------------------------------------------------------------------------------------
+OFA = CateDims(max_node=20, n_vocab=9, stagewise_pos=True)
+
+
+def make_pred_cate(seed=5):
+    d = PredictorCateDims()
+    m = mutils.create_model(predictor_cate_config(d, DEV))
+    m.load_state_dict(synthetic.predictor_cate_state_dict(d, seed=seed))
+    return m.eval()
+
+
+@pytest.mark.parametrize("mname", ["chain", "random"])
+def test_predictor_cate_and_guidance_gradient_golden(mname):
+    g = golden(f"predictor_ofa_{mname}")
+    clf = make_pred_cate(int(g["seed"]))
+    task = synthetic.synthetic_task(10, 20, seed=int(g["task_seed"])).to(DEV)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    X = torch.from_numpy(g["X"]).to(DEV)
+    B = X.shape[0]
+    m = torch.from_numpy(g["mask"]).to(DEV).unsqueeze(0).repeat(B, 1, 1)
+    clf.sample_state, clf.D_mu = True, None
+    gmax = mutils.get_classifier_grad_fn(sde, clf, train=False, continuous=True, regress=True, labels="max")
+    gmin = mutils.get_classifier_grad_fn(sde, clf, train=False, continuous=True, regress=True, labels="min")
+    for i, tval in enumerate(g["t"]):
+        t = torch.ones(B, device=DEV) * float(tval)
+        y = clf(X, t * 999, m, task=task.repeat(B, 1, 1))
+        assert y.shape == (B, 1)
+        close(y, g["y"][i], 1e-5, "y")
+        gr = gmax(X, t, m, task=task.repeat(B, 1, 1))
+        close(gr, g["grad"][i], 1e-5, "grad")
+        assert torch.equal(gmin(X, t, m[:1], task=task), -gr)      # shared mask (stride 0) gives the same bits
+    close(clf.D_mu[0], g["D_mu"], 5e-6, "D_mu")
+    clf.sample_state = False
+
+
+def test_predictor_cate_ragged_batch_per_graph_masks_matches_oracle():
+    """B not a multiple of the 3 graphs per workgroup, per-graph times and random masks (incl. fully
+    masked rows, whose scores pass no gradient)."""
+    from oracle import dnag_oracle as O
+    d = PredictorCateDims()
+    sdp = synthetic.predictor_cate_state_dict(d, seed=9)
+    clf = make_pred_cate(9)
+    task = synthetic.synthetic_task(10, 20, seed=3)
+    D_mu = O.set_encode(sdp, task)
+    rs = np.random.RandomState(10)
+    B = 131
+    X = torch.from_numpy(rs.standard_normal((B, 20, 9)).astype(np.float32))
+    t = torch.from_numpy(rs.uniform(1e-3, 1, B).astype(np.float32))
+    masks = torch.from_numpy((rs.uniform(0, 1, (B, 20, 20)) < 0.15).astype(np.float32))
+    masks[:, 19, :] = 0.0
+    ref_y = O.predictor_cate_forward(sdp, X, t * 999, masks, D_mu)
+    ref_g = O.classifier_grad_cate(sdp, X, t, masks, D_mu)
+    y = clf(X.to(DEV), (t * 999).to(DEV), masks.to(DEV), task=task.to(DEV))
+    gr = clf.input_grad(X.to(DEV), (t * 999).to(DEV), masks.to(DEV), task=task.to(DEV))
+    close(y, ref_y, 1e-5, "y")
+    close(gr, ref_g, 2e-5, "grad")
+    for b in (0, 1, 2, 129, 130):
+        close(gr[b], ref_g[b], 1e-4, f"grad[{b}]")
+
+
+def run_sampler_ofa(g, record=True):
+    B, S = int(g["B"]), int(g["n_run"])
+    cfg = score_config(OFA, DEV)
+    model = make_score(OFA, int(g["seed"]), preset=str(g["preset"]))
+    sde = sde_lib.VPSDE(0.1, float(g["beta_max"]), int(g["sde_N"]))
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 20, 9), utils.get_data_inverse_scaler(cfg), float(g["eps"]), conditional=True)
+    tape = synthetic.noise_tape(S, (B, 20, 9), int(g["tape_seed"]))
+    fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
+    fn.max_steps, fn.record = S, record
+    final = fn(model, torch.from_numpy(g["mask"]), make_pred_cate(int(g["pred_seed"])),
+               classifier_scale=float(g["classifier_scale"]), task=synthetic.synthetic_task(10, 20, seed=2))
+    return final, fn.last_record
+
+
+def test_pc_guided_ofa_first_steps_random_init():
+    g = golden("pc_guided_ofa_n1000_first6")
+    _, r = run_sampler_ofa(g)
+    for i in range(int(g["n_run"])):
+        close(r["rec_score_c"][i], g["score_c"][i], 1e-5, f"score_c[{i}]")
+        close(r["rec_cgrad_c"][i], g["cgrad_c"][i], 2e-5, f"cgrad_c[{i}]")
+        close(r["rec_x_corr"][i], g["x_corr"][i], 5e-6, f"x_corr[{i}]")
+        close(r["rec_x_pred"][i], g["x_pred"][i], 5e-6, f"x_pred[{i}]")
+
+
+def test_pc_guided_ofa_full_trajectory_contractive():
+    g = golden("pc_guided_ofa_contractive_n50")
+    final, r = run_sampler_ofa(g)
+    S = int(g["n_run"])
+    for i in (0, 1, S // 2, S - 1):
+        close(r["rec_x_pred"][i], g["x_pred"][i], 2e-4, f"x_pred[{i}]")
+        close(r["rec_score_p"][i], g["score_p"][i], 2e-4, f"score_p[{i}]")
+    close(final, g["final"], 2e-4, "final")
+    q = np.stack(utils.quantize(final))
+    assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
+
+
+def test_full_batch_guided_ofa_step_matches_oracle_on_a_slice():
+    """BASELINE config 4 shape: B=4096 OFA guided, 1 PC step; a 6-graph slice against the oracle."""
+    from oracle import dnag_oracle as O
+    B, S = 4096, 1
+    cfg = score_config(OFA, DEV)
+    sd = synthetic.cate_state_dict(OFA, seed=0)
+    sdp = synthetic.predictor_cate_state_dict(PredictorCateDims(), seed=5)
+    model, clf = make_score(OFA, 0), make_pred_cate(5)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 20, 9), utils.get_data_inverse_scaler(cfg), 1e-3, conditional=True)
+    tape = synthetic.noise_tape(S, (B, 20, 9), 22)
+    fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
+    fn.max_steps, fn.record = S, True
+    mask = synthetic.ofa_adjacency(20)
+    task = synthetic.synthetic_task(10, 20, seed=2)
+    fn(model, mask, clf, classifier_scale=1000.0, task=task)
+    r = {k: v.cpu() for k, v in fn.last_record.items()}
+    osde = O.VPSDE(0.1, 20.0, 1000)
+    ts = O.timesteps(osde, 1e-3)
+    D_mu = O.set_encode(sdp, task)
+    for sl in (slice(0, 3), slice(4093, 4096)):
+        mB = mask.unsqueeze(0).repeat(3, 1, 1)
+        vec_t = torch.ones(3) * ts[0]
+        s = O.score_fn(sd, osde, tape["x0"][sl], vec_t, mB, stagewise_pos=True)
+        cg = O.classifier_grad_cate(sdp, tape["x0"][sl], vec_t, mB, D_mu)
+        close(r["rec_score_c"][0][sl], s, 1e-5, "score_c")
+        close(r["rec_cgrad_c"][0][sl], cg, 2e-5, "cgrad_c")
+        close(r["rec_total_c"][0][sl], s + 1000.0 * cg, 2e-5, "total_c")
+    assert torch.isfinite(r["rec_x_pred"][0]).all()
