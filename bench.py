@@ -25,12 +25,12 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from diffusionnag_amd import _lib, mutils, sampling, sde_lib, synthetic, utils  # noqa: E402
-from diffusionnag_amd import cate as _cate, digcn_meta as _dm  # noqa: E402,F401
+from diffusionnag_amd import cate as _cate, digcn_meta as _dm, predictor_cate as _pcm  # noqa: E402,F401
 from diffusionnag_amd import distributed as D  # noqa: E402
-from diffusionnag_amd.specs import CateDims, PredictorDims  # noqa: E402
+from diffusionnag_amd.specs import CateDims, PredictorCateDims, PredictorDims  # noqa: E402
 
-# algorithmic FLOPs (2 per MAC) of one guided NB201 sample: SURVEY.md section 8d
-FLOP_PER_SAMPLE = 136.3e9
+# algorithmic FLOPs (2 per MAC) of one guided sample (2000 score evaluations + guidance gradients): SURVEY.md section 8d
+FLOP_PER_SAMPLE = {"nb201": 136.3e9, "ofa": 345.4e9}
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
@@ -39,10 +39,13 @@ class Cfg(dict):
     __setattr__ = dict.__setitem__
 
 
-def score_config(device):
-    d = CateDims()
+OFA_DIMS = CateDims(max_node=20, n_vocab=9, stagewise_pos=True)
+
+
+def score_config(device, d=CateDims()):
     ge = Cfg(n_layers=d.n_layers, d_model=d.d_model, n_head=d.n_head, d_ff=d.d_ff, dropout=0.1, n_vocab=d.n_vocab)
-    return Cfg(device=device, data=Cfg(name="NASBench201", max_node=8, n_vocab=7, centered=True),
+    return Cfg(device=device, data=Cfg(name="ofa" if d.stagewise_pos else "NASBench201", max_node=d.max_node,
+                                       n_vocab=d.n_vocab, centered=True),
                model=Cfg(name="CATE", nonlinearity="swish", dropout=0.1, pos_enc_type=2, graph_encoder=ge),
                training=Cfg(continuous=True),
                sampling=Cfg(method="pc", predictor="reverse_diffusion", corrector="langevin", snr=0.16, n_steps_each=1,
@@ -54,6 +57,14 @@ def predictor_config(device):
     ge = Cfg(initial_hidden=7, gcn_hidden=d.gcn_hidden, gcn_layers=d.gcn_layers, linear_hidden=d.linear_hidden)
     return Cfg(device=device, model=Cfg(name="MetaNeuralPredictor", nonlinearity="swish", input_type="DA", hs=d.hs,
                                         nz=d.nz, num_sample=d.num_sample, graph_encoder=ge))
+
+
+def predictor_cate_config(device):
+    d = PredictorCateDims()
+    ge = Cfg(n_layers=d.n_layers, d_model=d.d_model, n_head=d.n_head, d_ff=d.d_ff, dropout=0.1, n_vocab=d.n_vocab)
+    return Cfg(device=device, data=Cfg(name="ofa", max_node=d.max_node, n_vocab=d.n_vocab, centered=True),
+               model=Cfg(name="MetaPredictorCATE", nonlinearity="swish", dropout=0.1, input_type="DA", hs=d.hs, nz=d.nz,
+                         num_sample=d.num_sample, graph_encoder=ge))
 
 
 def cpu_baseline(seconds=12.0):
@@ -88,6 +99,9 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--sde-steps", type=int, default=1000, help="PC steps per trajectory (1000 = the full reverse SDE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["nb201", "ofa"], default="nb201",
+                    help="nb201 = BASELINE configs[1] (the headline metric); ofa = configs[3] (20x9 graphs, MetaPredictorCATE), "
+                         "a side measurement that never replaces the headline line")
     a = ap.parse_args()
 
     rank, world, local = D.init_from_env()
@@ -98,23 +112,33 @@ def main():
     B = a.batch_per_gpu
     total = B * world
 
-    cfg = score_config(dev)
+    ofa = a.workload == "ofa"
+    dims = OFA_DIMS if ofa else CateDims()
+    N, V = dims.max_node, dims.n_vocab
+    cfg = score_config(dev, dims)
     model = mutils.create_model(cfg)
-    model.load_state_dict(synthetic.cate_state_dict(CateDims(), seed=0))
-    clf = mutils.create_model(predictor_config(dev))
-    clf.load_state_dict(synthetic.predictor_state_dict(PredictorDims(), seed=1))
+    model.load_state_dict(synthetic.cate_state_dict(dims, seed=0))
+    if ofa:
+        clf = mutils.create_model(predictor_cate_config(dev))
+        clf.load_state_dict(synthetic.predictor_cate_state_dict(PredictorCateDims(), seed=5))
+        mask = synthetic.ofa_adjacency(N).to(dev)                # chain DAG (MobileNetV3/main_exp/diffusion/run_lib.py:147-153)
+        cscale = 1000.0
+    else:
+        clf = mutils.create_model(predictor_config(dev))
+        clf.load_state_dict(synthetic.predictor_state_dict(PredictorDims(), seed=1))
+        mask = utils.aug_mask(utils.nb201_adj())[0].to(dev)      # Floyd closure, as generate_archs_meta builds it
+        cscale = 10000.0
     task = synthetic.synthetic_task(10, 20, seed=2).to(dev)
-    mask = utils.aug_mask(utils.nb201_adj())[0].to(dev)          # Floyd closure, as generate_archs_meta builds it
     sde = sde_lib.VPSDE(beta_min=0.1, beta_max=20.0, N=1000)
-    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3, conditional=True)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, N, V), utils.get_data_inverse_scaler(cfg), 1e-3, conditional=True)
     if a.sde_steps != 1000:
         fn.max_steps = a.sde_steps                               # debugging only: the reported metric needs 1000
     start, _ = D.shard_batch(total, rank, world)
-    D.configure_sampler_shard(fn, start, 8, 7, seed=1234)
+    D.configure_sampler_shard(fn, start, N, V, seed=1234)
     torch.manual_seed(1000 + rank)                               # x0 is drawn on the CPU generator, like the reference
 
     def step():
-        x = fn(model, mask, clf, classifier_scale=10000.0, task=task)
+        x = fn(model, mask, clf, classifier_scale=cscale, task=task)
         return D.gather_samples(x, total)
 
     def fence():
@@ -146,25 +170,30 @@ def main():
     if rank == 0:
         value = total * a.steps / dt
         achieved = flops.value / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
+        flop_per_sample = FLOP_PER_SAMPLE[a.workload]
         line = {
-            "metric": "guided arch samples/sec (full reverse SDE), NB201", "value": value, "unit": "samples/s",
+            "metric": "guided arch samples/sec (full reverse SDE), " + ("OFA" if ofa else "NB201"), "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: NAS-Bench-201 predictor-guided sampling (meta-predictor gradient), "
-                                   f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
-                                   "snr 0.16, classifier_scale 1e4, Floyd-closure mask, random-init weights (seeded), "
-                                   "Philox noise on device",
+            "config": {"workload": ("BASELINE configs[3]: MobileNetV3/OFA 20-node graphs, guided sampling (MetaPredictorCATE gradient), "
+                                    f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
+                                    "snr 0.16, classifier_scale 1e3, chain mask, random-init weights (seeded), Philox noise on device")
+                       if ofa else
+                                   ("BASELINE configs[1]: NAS-Bench-201 predictor-guided sampling (meta-predictor gradient), "
+                                    f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
+                                    "snr 0.16, classifier_scale 1e4, Floyd-closure mask, random-init weights (seeded), "
+                                    "Philox noise on device"),
                        "batch_per_gpu": B, "global_batch": total, "pc_steps": a.sde_steps,
                        "score_evals_per_sample": 2 * a.sde_steps, "parallelism": f"batch-shard x{world}"},
             "roofline": {"bound": "mfma", "kernel": "gemm_bias_act_kernel<true,1> (final.linears.1, M x 1536 x 1536, fp32 MFMA)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                          "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value},
-            "whole_path_tflops": value * FLOP_PER_SAMPLE * (a.sde_steps / 1000.0) / 1e12 / world,
-            "whole_path_frac_of_f32_mfma_peak": value * FLOP_PER_SAMPLE * (a.sde_steps / 1000.0) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
+            "whole_path_tflops": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world,
+            "whole_path_frac_of_f32_mfma_peak": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
             "outputs_finite": finite,
         }
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and not ofa:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
