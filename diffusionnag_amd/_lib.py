@@ -17,7 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdnag.so")
 
 SCHED_COLS = 8
-SCHED_LABEL, SCHED_STD, SCHED_ALPHA, SCHED_SQRTA, SCHED_G, SCHED_G2, SCHED_T = range(7)
+SCHED_LABEL, SCHED_STD, SCHED_ALPHA, SCHED_SQRTA, SCHED_G, SCHED_G2, SCHED_T, SCHED_DT = range(8)
+PREDICTOR_NONE, PREDICTOR_REVERSE_DIFFUSION, PREDICTOR_EULER_MARUYAMA = range(3)
+SCORE_VP, SCORE_VE = range(2)
 
 # every symbol include/dnag.h declares (tests check that the built library exports them all)
 EXPORTS = (
@@ -56,7 +58,8 @@ class PcArgsC(C.Structure):
         ("predcate_dims", C.POINTER(PredCateDimsC)), ("predcate_packed", _fp), ("d_mu", _fp),
         ("classifier_scale", C.c_float), ("label_sign", C.c_float),
         ("batch", C.c_int32), ("mask", _fp), ("sched", _fp), ("n_steps", C.c_int32),
-        ("snr", C.c_float), ("corrector", C.c_int32),
+        ("snr", C.c_float), ("corrector", C.c_int32), ("predictor", C.c_int32), ("score_mode", C.c_int32),
+        ("prior_scale", C.c_float),
         ("x0", _fp), ("noise_corr", _fp), ("noise_pred", _fp),
         ("seed", C.c_uint64), ("stream_offset", C.c_uint64),
         ("x_out", _fp), ("x_last", _fp), ("x_mean_last", _fp),

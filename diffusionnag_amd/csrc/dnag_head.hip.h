@@ -145,6 +145,8 @@ struct ExitArgs {
     int mode;
     int batch;
     // score scaling / guidance
+    int score_mode;               // DNAG_SCORE_VP: score = -out / std; DNAG_SCORE_VE: score = out
+    int pred_kind;                // DNAG_PREDICTOR_REVERSE_DIFFUSION or _EULER_MARUYAMA (EXIT_PREDICTOR)
     float std;                    // marginal std at t          (EXIT_CORRECTOR / EXIT_PREDICTOR)
     float cscale;                 // classifier_scale * label sign; cgrad may be null
     const float *cgrad;           // [batch][N][V]
@@ -157,7 +159,8 @@ struct ExitArgs {
     // EXIT_PREDICTOR
     float *x;                     // state, updated in place
     float *x_mean;                // [batch][N][V]
-    float sqrt_alpha, G, G2;
+    float sqrt_alpha, G, G2;      // sched columns SQRTA, G, G2 (their Euler-Maruyama meaning: include/dnag.h)
+    float dt;                     // sched column DT
     // noise of this exit (corrector: only its norm is needed here)
     const float *noise;           // tape slice [batch][N][V] or null -> Philox
     uint64_t seed, stream_offset;
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
                 if (a.out_gstride) a.out[(size_t)(blockIdx.x * GF + g) * a.out_gstride + (rr - g * N) * V + v] = val;
                 else a.out[e] = val;
             } else {
-                const float score = __fdiv_rn(-val, a.std);                       // models/utils.py:103
+                const float score = a.score_mode == DNAG_SCORE_VP ? __fdiv_rn(-val, a.std) : val;   // models/utils.py:103 | :116
                 total = score;
                 if (a.cgrad != nullptr) total = __fadd_rn(score, __fmul_rn(a.cscale, a.cgrad[e]));  // sampling.py:505
                 if (a.rec_score) a.rec_score[e] = score;
@@ -241,9 +244,17 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
                 } else {
                     // f = sqrt(alpha) x - x ; rev_f = f - G^2 total ; x_mean = x - rev_f ; x = x_mean + G z
                     const float xv = a.x[e];
-                    const float f = __fsub_rn(__fmul_rn(a.sqrt_alpha, xv), xv);
-                    const float rev_f = __fsub_rn(f, __fmul_rn(a.G2, total));
-                    const float xm = __fsub_rn(xv, rev_f);
+                    float xm;
+                    if (a.pred_kind == DNAG_PREDICTOR_EULER_MARUYAMA) {
+                        // drift = c x - diffusion^2 total ; x_mean = x + drift dt ; x = x_mean + diffusion sqrt(-dt) z
+                        // (sampling.py:194-200, sde_lib.py:95-103; a VESDE has c = 0)
+                        const float drift = __fsub_rn(__fmul_rn(a.sqrt_alpha, xv), __fmul_rn(a.G2, total));
+                        xm = __fadd_rn(xv, __fmul_rn(drift, a.dt));
+                    } else {
+                        const float f = __fsub_rn(__fmul_rn(a.sqrt_alpha, xv), xv);
+                        const float rev_f = __fsub_rn(f, __fmul_rn(a.G2, total));
+                        xm = __fsub_rn(xv, rev_f);
+                    }
                     const float xn = __fadd_rn(xm, __fmul_rn(a.G, noise));
                     a.x_mean[e] = xm;
                     a.x[e] = xn;
@@ -326,9 +337,9 @@ __global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
 }
 
 // x0 = prior sample (sde_lib.py:190-191): copy of the caller's tensor, or Philox draw 0.
-__global__ void prior_kernel(float *x, const float *x0, size_t nelem, uint64_t seed, uint64_t stream_offset) {
+__global__ void prior_kernel(float *x, const float *x0, size_t nelem, uint64_t seed, uint64_t stream_offset, float scale) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (size_t)gridDim.x * blockDim.x)
-        x[e] = x0 ? x0[e] : philox_normal(seed, stream_offset + e, 0u);
+        x[e] = x0 ? x0[e] : __fmul_rn(philox_normal(seed, stream_offset + e, 0u), scale);
 }
 
 // out = (x_mean + 1) / 2  (datasets_nas.py:21-28)

@@ -699,6 +699,10 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     }
     if (!p->cate_packed || !p->mask || !p->sched || !p->x_out || !p->workspace) return fail(DNAG_E_ARG, "NULL pointer");
     if (p->batch < 1 || p->n_steps < 1) return fail(DNAG_E_ARG, "batch=%d n_steps=%d", p->batch, p->n_steps);
+    if (p->predictor < DNAG_PREDICTOR_NONE || p->predictor > DNAG_PREDICTOR_EULER_MARUYAMA)
+        return fail(DNAG_E_ARG, "predictor=%d is not a DNAG_PREDICTOR_* value", p->predictor);
+    if (p->score_mode != DNAG_SCORE_VP && p->score_mode != DNAG_SCORE_VE) return fail(DNAG_E_ARG, "score_mode=%d", p->score_mode);
+    if (!p->x0 && !(p->prior_scale > 0.f)) return fail(DNAG_E_ARG, "prior_scale=%g must be positive when x0 is NULL", p->prior_scale);
     if ((p->noise_corr == nullptr) != (p->noise_pred == nullptr) && p->corrector)
         return fail(DNAG_E_ARG, "noise_corr and noise_pred must both be given (tape mode) or both NULL (Philox)");
     const dnag_cate_dims &cd = *p->cate_dims;
@@ -720,7 +724,8 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     std::vector<float> labels(S);
     for (int i = 0; i < S; ++i) {
         const float *row = p->sched + (size_t)i * DNAG_SCHED_COLS;
-        if (!(row[DNAG_SCHED_STD] > 0.f)) return fail(DNAG_E_ARG, "sched[%d].std = %g is not positive", i, row[DNAG_SCHED_STD]);
+        if (p->score_mode == DNAG_SCORE_VP && !(row[DNAG_SCHED_STD] > 0.f))
+            return fail(DNAG_E_ARG, "sched[%d].std = %g is not positive", i, row[DNAG_SCHED_STD]);
         labels[i] = row[DNAG_SCHED_LABEL];
     }
     HIP_TRY(hipMemcpyAsync(ws + w.labels, labels.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
@@ -735,14 +740,15 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     }
 
     float *x = ws + w.x, *x_mean = ws + w.x_mean, *cgrad = ws + w.cgrad, *gbuf = ws + w.gbuf, *partials = ws + w.partials;
-    hipLaunchKernelGGL(prior_kernel, dim3(1024), dim3(256), 0, st, x, p->x0, nelem, p->seed, p->stream_offset);
+    hipLaunchKernelGGL(prior_kernel, dim3(1024), dim3(256), 0, st, x, p->x0, nelem, p->seed, p->stream_offset, p->prior_scale);
     LAUNCH_CHECK();
 
     auto rec_at = [&](float *base, int i) -> float * { return base ? base + (size_t)i * nelem : nullptr; };
 
     for (int i = 0; i < S; ++i) {
         const float *row = p->sched + (size_t)i * DNAG_SCHED_COLS;
-        for (int phase = p->corrector ? 0 : 1; phase < 2; ++phase) {
+        // phase 0: corrector, phase 1: predictor; a None corrector / predictor evaluates nothing (sampling.py:216-224, :259-267)
+        for (int phase = p->corrector ? 0 : 1; phase < (p->predictor == DNAG_PREDICTOR_NONE ? 1 : 2); ++phase) {
             const bool corr = phase == 0;
             if (guided) {
                 if (guided_pc) {
@@ -757,6 +763,7 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             a.mode = corr ? EXIT_CORRECTOR : EXIT_PREDICTOR;
             a.batch = B;
             a.std = row[DNAG_SCHED_STD];
+            a.score_mode = p->score_mode; a.pred_kind = p->predictor; a.dt = row[DNAG_SCHED_DT];
             a.cgrad = guided ? cgrad : nullptr;
             a.cscale = p->classifier_scale * p->label_sign;
             a.gbuf = gbuf; a.partials = partials;
@@ -785,6 +792,8 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             }
         }
     }
+    // NonePredictor returns (x, x): the state after the last corrector (or the prior) is also x_mean
+    if (p->predictor == DNAG_PREDICTOR_NONE) HIP_TRY(hipMemcpyAsync(x_mean, x, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(inverse_scale_kernel, dim3(1024), dim3(256), 0, st, x_mean, p->x_out, nelem);
     LAUNCH_CHECK();
     if (p->x_last) HIP_TRY(hipMemcpyAsync(p->x_last, x, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -49,8 +49,9 @@ def get_model_fn(model, train=False):
 
 
 def get_score_fn(sde, model, train=False, continuous=False):
-    """Reference ``models/utils.py:73-123`` for VPSDE with ``continuous=True``:
-    ``labels = 999 t`` and ``score = -model(x, labels, mask) / std``."""
+    """Reference ``models/utils.py:73-123`` with ``continuous=True``.  VPSDE: ``labels = 999 t`` and
+    ``score = -model(x, labels, mask) / std``; VESDE: ``labels = sigma(t)`` and the model output is
+    the score."""
     model_fn = get_model_fn(model, train=train)
     if isinstance(sde, sde_lib.VPSDE):
         if not continuous:
@@ -62,19 +63,26 @@ def get_score_fn(sde, model, train=False, continuous=False):
             score = model_fn(x, labels, *args, **kwargs)
             std = sde.marginal_prob(torch.zeros_like(x), t)[1]
             return -score / std[:, None, None]
+    elif isinstance(sde, sde_lib.VESDE):
+        if not continuous:
+            raise NotImplementedError("only continuous=True is supported (as in the reference's shipped configs)")
+
+        def score_fn(x, t, *args, **kwargs):
+            labels = sde.marginal_prob(torch.zeros_like(x), t)[1]          # models/utils.py:109
+            return model_fn(x, labels, *args, **kwargs)
     else:
         raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
     return score_fn
 
 
 def get_logit_fn(sde, classifier, train=False, continuous=False):
-    """Reference ``models/utils.py:150-179`` (VPSDE, continuous)."""
+    """Reference ``models/utils.py:150-179`` (continuous): the surrogate is conditioned like the score net."""
     classifier_fn = get_model_fn(classifier, train=train)
-    if not isinstance(sde, sde_lib.VPSDE) or not continuous:
-        raise NotImplementedError("only a continuously trained VPSDE surrogate is supported")
+    if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE)) or not continuous:
+        raise NotImplementedError("only a continuously trained VPSDE / VESDE surrogate is supported")
 
     def logit_fn(x, t, *args, **kwargs):
-        return classifier_fn(x, t * 999, *args, **kwargs)
+        return classifier_fn(x, sde.time_cond(t), *args, **kwargs)
 
     return logit_fn
 
@@ -83,8 +91,8 @@ def get_classifier_grad_fn(sde, classifier, train=False, continuous=False, regre
     """Reference ``models/utils.py:126-147`` with ``regress=True``.  The reference differentiates
     ``+-logit.sum()`` with autograd; the surrogate module exposes the same quantity through the
     hand-derived backward pass of the HIP kernel (``input_grad``)."""
-    if not isinstance(sde, sde_lib.VPSDE) or not continuous:
-        raise NotImplementedError("only a continuously trained VPSDE surrogate is supported")
+    if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE)) or not continuous:
+        raise NotImplementedError("only a continuously trained VPSDE / VESDE surrogate is supported")
     if not regress:
         raise NotImplementedError("classification guidance (regress=False) is not on the hot path")
     assert labels in ['max', 'min']
@@ -93,7 +101,7 @@ def get_classifier_grad_fn(sde, classifier, train=False, continuous=False, regre
         if train:
             raise NotImplementedError("train=True is not supported on the HIP path")
         classifier.eval()
-        grad = classifier.input_grad(x, t * 999, *args, **kwargs)
+        grad = classifier.input_grad(x, sde.time_cond(t), *args, **kwargs)
         return grad if labels == 'max' else -grad
 
     return classifier_grad_fn

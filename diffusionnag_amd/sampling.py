@@ -64,18 +64,25 @@ def get_corrector(name):
 class ReverseDiffusionPredictor:
     """Reference ``sampling.py:203-213``; fused into ``head_out_kernel`` (EXIT_PREDICTOR)."""
     fused = True
+    kind = _lib.PREDICTOR_REVERSE_DIFFUSION
+    table = "reverse_diffusion"
 
 
 @register_predictor(name='euler_maruyama')
 class EulerMaruyamaPredictor:
-    """Reference ``sampling.py:189-200``; a "next" row, not built yet."""
-    fused = False
+    """Reference ``sampling.py:189-200`` (the shipped default); the same exit kernel with the
+    Euler-Maruyama scalars of ``sde_lib.schedule_table``."""
+    fused = True
+    kind = _lib.PREDICTOR_EULER_MARUYAMA
+    table = "euler_maruyama"
 
 
 @register_predictor(name='none')
 class NonePredictor:
-    """Reference ``sampling.py:216-224``; not built."""
-    fused = False
+    """Reference ``sampling.py:216-224``: identity, no score evaluation."""
+    fused = True
+    kind = _lib.PREDICTOR_NONE
+    table = "reverse_diffusion"
 
 
 @register_corrector(name='langevin')
@@ -119,10 +126,10 @@ class _PCSampler:
 
     def __init__(self, sde, shape, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow, continuous,
                  denoise, eps, device, noise):
-        if not isinstance(sde, sde_lib.VPSDE):
+        if not isinstance(sde, (sde_lib.VPSDE, sde_lib.VESDE)):
             raise NotImplementedError(f"SDE class {sde.__class__.__name__} not yet supported.")
         if not getattr(predictor, "fused", False):
-            raise NotImplementedError(f"predictor {predictor.__name__} is not built (only 'reverse_diffusion')")
+            raise NotImplementedError(f"predictor {predictor.__name__} is not built")
         if not getattr(corrector, "fused", False):
             raise NotImplementedError(f"corrector {corrector.__name__} is not built (only 'langevin' and 'none')")
         if probability_flow:
@@ -133,7 +140,7 @@ class _PCSampler:
             raise NotImplementedError("n_steps_each != 1 is not built (every shipped config uses 1)")
         if noise not in ("philox", "torch"):
             raise ValueError(f"config.sampling.noise={noise!r}: expected 'philox' or 'torch'")
-        self.sde, self.shape, self.corrector = sde, tuple(shape), corrector
+        self.sde, self.shape, self.corrector, self.predictor = sde, tuple(shape), corrector, predictor
         self.inverse_scaler, self.snr, self.n_steps, self.denoise = inverse_scaler, snr, n_steps, denoise
         self.eps, self.device, self.noise = eps, torch.device(device), noise
         self.noise_tape: Optional[dict] = None
@@ -155,7 +162,7 @@ class _PCSampler:
             raise TypeError("score_model must be diffusionnag_amd.cate.CATE (create it with mutils.create_model)")
         B, N, V = self.shape
         S = self.sde.N if self.max_steps is None else int(self.max_steps)
-        sched = self.sde.schedule_table(self.eps, S)
+        sched = self.sde.schedule_table(self.eps, S, self.predictor.table)
         score_model.eval()
         cd = score_model.dims_c()
         if (N, V) != (cd.max_node, cd.n_vocab):
@@ -194,6 +201,9 @@ class _PCSampler:
         args.sched = sched.ctypes.data
         args.snr = float(self.snr)
         args.corrector = int(self.corrector.enabled)
+        args.predictor = int(self.predictor.kind)
+        args.score_mode = int(self.sde.score_mode)
+        args.prior_scale = float(self.sde.prior_scale)
         # noise ------------------------------------------------------------------------------------
         tape = self.noise_tape
         if tape is None:
@@ -205,7 +215,8 @@ class _PCSampler:
                 for i in range(S):
                     if self.corrector.enabled:
                         nc[i] = torch.randn_like(x0)
-                    npd[i] = torch.randn_like(x0)
+                    if self.predictor.kind != _lib.PREDICTOR_NONE:
+                        npd[i] = torch.randn_like(x0)
                 tape = {"x0": x0, "corrector": nc, "predictor": npd}
             else:
                 tape = {"x0": x0, "corrector": None, "predictor": None}

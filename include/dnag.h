@@ -129,19 +129,31 @@ int dnag_predcate_forward_grad(const dnag_predcate_dims *d, const float *packed,
 
 /* ---- predictor-corrector sampler -------------------------------------------------------------
  * Replaces the loops of pc_sampler (sampling.py:424-445) and pc_conditional_sampler
- * (sampling.py:534-577) for ReverseDiffusionPredictor (sampling.py:203-213) + LangevinCorrector
- * (sampling.py:227-256) on a VPSDE (sde_lib.py:145-211), continuous=True, probability_flow=False.
+ * (sampling.py:534-577): predictors ReverseDiffusionPredictor (sampling.py:203-213),
+ * EulerMaruyamaPredictor (:189-200), NonePredictor (:216-224); correctors LangevinCorrector
+ * (:227-256), NoneCorrector (:259-267); on a VPSDE (sde_lib.py:145-211) or a VESDE (:253-300),
+ * continuous=True, probability_flow=False.
  *
- * `sched` is a HOST array [n_steps][DNAG_SCHED_COLS] built by the host mirror of VPSDE
- * (diffusionnag_amd/sde_lib.py) with the reference's own fp32 arithmetic. */
+ * `sched` is a HOST array [n_steps][DNAG_SCHED_COLS] built by the host mirrors of VPSDE / VESDE
+ * (diffusionnag_amd/sde_lib.py) with the reference's own fp32 arithmetic.  Columns, VPSDE first: */
 #define DNAG_SCHED_COLS 8
-#define DNAG_SCHED_LABEL 0  /* 999 * t_i                       (models/utils.py:93)  */
-#define DNAG_SCHED_STD   1  /* marginal_prob std at t_i        (sde_lib.py:179-188)  */
-#define DNAG_SCHED_ALPHA 2  /* alphas[k_i]                     (sampling.py:238-240) */
-#define DNAG_SCHED_SQRTA 3  /* sqrt(alphas[k_i])               (sde_lib.py:203)      */
-#define DNAG_SCHED_G     4  /* sqrt(discrete_betas[k_i])       (sde_lib.py:204)      */
-#define DNAG_SCHED_G2    5  /* G * G in fp32                   (sde_lib.py:122)      */
-#define DNAG_SCHED_T     6  /* t_i                                                   */
+#define DNAG_SCHED_LABEL 0  /* time_cond: 999 t_i (models/utils.py:93) | sigma(t_i) (:109)                        */
+#define DNAG_SCHED_STD   1  /* marginal_prob std at t_i (sde_lib.py:179-188) | unused (score is not rescaled, :116) */
+#define DNAG_SCHED_ALPHA 2  /* alphas[k_i] (sampling.py:238-240) | 1 (:242)                                        */
+#define DNAG_SCHED_SQRTA 3  /* reverse_diffusion: sqrt(alphas[k_i]) (sde_lib.py:203-207) | 1 (f = 0, :298)
+                             * euler_maruyama:    -0.5 beta(t_i) (sde_lib.py:169-173) | 0 (:274)                   */
+#define DNAG_SCHED_G     4  /* reverse_diffusion: G = sqrt(discrete_betas[k_i]) (sde_lib.py:204) |
+                             *                        sqrt(sigma_k^2 - sigma_{k-1}^2) (:299)
+                             * euler_maruyama:    diffusion * sqrt(-dt) (sampling.py:199)                          */
+#define DNAG_SCHED_G2    5  /* reverse_diffusion: G * G in fp32 (sde_lib.py:122); euler_maruyama: diffusion ** 2 (:100) */
+#define DNAG_SCHED_T     6  /* t_i                                                                                 */
+#define DNAG_SCHED_DT    7  /* euler_maruyama: dt = -1/N (sampling.py:195)                                         */
+
+#define DNAG_PREDICTOR_NONE              0
+#define DNAG_PREDICTOR_REVERSE_DIFFUSION 1
+#define DNAG_PREDICTOR_EULER_MARUYAMA    2
+#define DNAG_SCORE_VP 0     /* score = -model / std  (models/utils.py:103) */
+#define DNAG_SCORE_VE 1     /* score = model         (models/utils.py:116-117) */
 
 typedef struct dnag_pc_args {
     /* networks */
@@ -161,6 +173,9 @@ typedef struct dnag_pc_args {
     int32_t n_steps;                   /* number of PC steps to run (sde.N for a full trajectory) */
     float snr;                         /* sampling.py:251 */
     int32_t corrector;                 /* 1: LangevinCorrector, 0: NoneCorrector */
+    int32_t predictor;                 /* DNAG_PREDICTOR_* */
+    int32_t score_mode;                /* DNAG_SCORE_VP or DNAG_SCORE_VE */
+    float prior_scale;                 /* x0 = prior_scale * N(0,1) when x0 == NULL: 1 (sde_lib.py:191) | sigma_max (:285) */
     /* noise: tape mode if noise_corr/noise_pred != NULL ([n_steps][batch][N][V] each, device,
      * the order of randn_like at sampling.py:247 and :210); otherwise on-device Philox4x32-10 +
      * Box-Muller keyed by (seed, stream_offset + element index, step). */

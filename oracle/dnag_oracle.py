@@ -100,6 +100,63 @@ class VPSDE:
         G = torch.sqrt(beta)
         return f, G
 
+    def sde(self, x: Tensor, t: Tensor):
+        """sde_lib.py:168-177."""
+        beta_t = self.beta_0 + t * (self.beta_1 - self.beta_0)
+        return -0.5 * beta_t[:, None, None] * x, torch.sqrt(beta_t)
+
+    def langevin_alpha(self, t: Tensor) -> Tensor:
+        """sampling.py:237-240."""
+        return self.alphas[self.timestep_index(t)]
+
+    def time_cond(self, t: Tensor) -> Tensor:
+        """models/utils.py:93 (continuous=True)."""
+        return t * 999
+
+    def prior_sampling(self, shape) -> Tensor:
+        """sde_lib.py:190-191."""
+        return torch.randn(*shape)
+
+
+class VESDE:
+    """Variance-exploding SDE, sde_lib.py:253-300."""
+
+    def __init__(self, sigma_min: float = 0.01, sigma_max: float = 50.0, N: int = 1000):
+        self.sigma_min, self.sigma_max, self.N, self.T = sigma_min, sigma_max, N, 1
+        self.discrete_sigmas = torch.exp(torch.linspace(math.log(sigma_min), math.log(sigma_max), N))   # :265
+
+    def marginal_std(self, t: Tensor) -> Tensor:
+        """sde_lib.py:279-282."""
+        return self.sigma_min * (self.sigma_max / self.sigma_min) ** t
+
+    def timestep_index(self, t: Tensor) -> Tensor:
+        return (t * (self.N - 1) / self.T).long()
+
+    def discretize(self, x: Tensor, t: Tensor):
+        """SMLD discretisation, sde_lib.py:292-300."""
+        k = self.timestep_index(t)
+        sigma = self.discrete_sigmas[k]
+        adjacent = torch.where(k == 0, torch.zeros_like(t), self.discrete_sigmas[k - 1])
+        return torch.zeros_like(x), torch.sqrt(sigma ** 2 - adjacent ** 2)
+
+    def sde(self, x: Tensor, t: Tensor):
+        """sde_lib.py:272-277."""
+        sigma = self.sigma_min * (self.sigma_max / self.sigma_min) ** t
+        diffusion = sigma * torch.sqrt(torch.tensor(2 * (math.log(self.sigma_max) - math.log(self.sigma_min))))
+        return torch.zeros_like(x), diffusion
+
+    def langevin_alpha(self, t: Tensor) -> Tensor:
+        """sampling.py:241-242."""
+        return torch.ones_like(t)
+
+    def time_cond(self, t: Tensor) -> Tensor:
+        """models/utils.py:109 (continuous=True): the noise level."""
+        return self.marginal_std(t)
+
+    def prior_sampling(self, shape) -> Tensor:
+        """sde_lib.py:284-285."""
+        return torch.randn(*shape) * self.sigma_max
+
 
 def timesteps(sde: VPSDE, eps: float) -> Tensor:
     """sampling.py:437."""
@@ -193,8 +250,11 @@ def cate_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, *, n_layer
     return mlp_head(sd, "final", h, 3)                                          # cate.py:162
 
 
-def score_fn(sd: SD, sde: VPSDE, x: Tensor, t: Tensor, maskX: Tensor, **kw) -> Tensor:
-    """models/utils.py:88-104 (continuous=True): labels = 999 t, score = -model/std."""
+def score_fn(sd: SD, sde, x: Tensor, t: Tensor, maskX: Tensor, **kw) -> Tensor:
+    """models/utils.py:88-104 (VPSDE, continuous=True): labels = 999 t, score = -model/std;
+    models/utils.py:106-117 (VESDE): labels = sigma(t), the model output is the score."""
+    if isinstance(sde, VESDE):
+        return cate_forward(sd, x, sde.time_cond(t), maskX, **kw)
     out = cate_forward(sd, x, t * 999, maskX, **kw)
     std = sde.marginal_std(t)
     return -out / std[:, None, None]
@@ -262,11 +322,12 @@ def predictor_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, D_mu:
     return _lin(sd, "pred_fc.2", torch.tanh(_lin(sd, "pred_fc.0", vec)))        # :148
 
 
-def classifier_grad(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tensor, labels: str = "max") -> Tensor:
-    """models/utils.py:130-145 (regress=True): d/dx of +-sum_b f(x_b); logit_fn labels = 999 t (:159)."""
+def classifier_grad(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tensor, labels: str = "max", sde=None) -> Tensor:
+    """models/utils.py:130-145 (regress=True): d/dx of +-sum_b f(x_b); logit_fn labels = 999 t (:159),
+    or sigma(t) for a VESDE (:170)."""
     with torch.enable_grad():
         x_in = x.detach().clone().requires_grad_(True)
-        logit = predictor_forward(sd, x_in, t * 999, maskX, D_mu)
+        logit = predictor_forward(sd, x_in, t * 999 if sde is None else sde.time_cond(t), maskX, D_mu)
         prob = logit.sum() if labels == "max" else -logit.sum()
         return torch.autograd.grad(prob, x_in)[0]
 
@@ -289,11 +350,11 @@ def predictor_cate_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, 
     return _lin(sd, "pred_fc.2", torch.tanh(_lin(sd, "pred_fc.0", vec)))         # :348
 
 
-def classifier_grad_cate(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tensor, labels: str = "max") -> Tensor:
+def classifier_grad_cate(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tensor, labels: str = "max", sde=None) -> Tensor:
     """models/utils.py:130-145 (regress=True) for the OFA surrogate."""
     with torch.enable_grad():
         x_in = x.detach().clone().requires_grad_(True)
-        logit = predictor_cate_forward(sd, x_in, t * 999, maskX, D_mu)
+        logit = predictor_cate_forward(sd, x_in, t * 999 if sde is None else sde.time_cond(t), maskX, D_mu)
         prob = logit.sum() if labels == "max" else -logit.sum()
         return torch.autograd.grad(prob, x_in)[0]
 
@@ -302,14 +363,16 @@ def classifier_grad_cate(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tens
 # predictor-corrector loop (sampling.py:203-256, :424-445, :496-577)
 # ----------------------------------------------------------------------------------------------
 
-def pc_sample(score_sd: SD, sde: VPSDE, mask: Tensor, tape: dict, *, eps: float = 1e-3, snr: float = 0.16,
+def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3, snr: float = 0.16,
               n_steps: Optional[int] = None, pred_sd: Optional[SD] = None, D_mu: Optional[Tensor] = None,
               classifier_scale: float = 0.0, labels: str = "max", record: Optional[list] = None,
-              model_kw: Optional[dict] = None) -> Tensor:
-    """Reverse-diffusion predictor + Langevin corrector with injected noise.
+              model_kw: Optional[dict] = None, predictor: str = "reverse_diffusion", corrector: str = "langevin") -> Tensor:
+    """Predictor-corrector loop with injected noise (sampling.py:424-445 / :534-577).
 
+    ``predictor``: 'reverse_diffusion' (sampling.py:203-213), 'euler_maruyama' (:189-200) or 'none'
+    (:216-224); ``corrector``: 'langevin' (:227-256) or 'none' (:259-267); ``sde``: VPSDE or VESDE.
     ``tape`` = {'x0': [B,N,V], 'corrector': [S,B,N,V], 'predictor': [S,B,N,V]} replaces
-    ``prior_sampling`` (sampling.py:436), ``randn_like`` at :247 and at :210, in that order.
+    ``prior_sampling`` (sampling.py:436), ``randn_like`` at :247 and at :210 / :196, in that order.
     ``n_steps`` truncates the loop (the time grid is always the full ``linspace(T, eps, sde.N)``).
     Returns ``inverse_scaler(x_mean_last)`` (sampling.py:445 / :577, noise_removal=True).
     """
@@ -325,7 +388,7 @@ def pc_sample(score_sd: SD, sde: VPSDE, mask: Tensor, tape: dict, *, eps: float 
         if pred_sd is None:
             return s, s, None
         grad_fn = classifier_grad_cate if "regeress.linears.0.weight" in pred_sd else classifier_grad
-        cg = grad_fn(pred_sd, x, vec_t, maskX, D_mu, labels)
+        cg = grad_fn(pred_sd, x, vec_t, maskX, D_mu, labels, sde)
         return s + classifier_scale * cg, s, cg
 
     x_mean = x
@@ -333,26 +396,43 @@ def pc_sample(score_sd: SD, sde: VPSDE, mask: Tensor, tape: dict, *, eps: float 
         for i in range(S):
             vec_t = torch.ones(B) * ts[i]                                       # :442
             rec = {"x_in": x.clone()} if record is not None else None
-            # -- LangevinCorrector.update_fn, sampling.py:232-256
-            k = sde.timestep_index(vec_t)
-            alpha = sde.alphas[k]
-            grad, s1, cg1 = total_grad(x, vec_t)
-            noise = tape["corrector"][i]
-            grad_norm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
-            noise_norm = torch.norm(noise.reshape(B, -1), dim=-1).mean()
-            step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
-            x_mean = x + step_size[:, None, None] * grad
-            x = x_mean + torch.sqrt(step_size * 2)[:, None, None] * noise
-            if rec is not None:
-                rec.update(score_c=s1, cgrad_c=cg1, total_c=grad, grad_norm=grad_norm, noise_norm=noise_norm,
-                           step_size=step_size[0].clone(), x_corr=x.clone())
-            # -- ReverseDiffusionPredictor.update_fn, sampling.py:208-213 + sde_lib.py:119-125
-            f, G = sde.discretize(x, vec_t)
-            grad2, s2, cg2 = total_grad(x, vec_t)
-            rev_f = f - G[:, None, None] ** 2 * grad2
-            z = tape["predictor"][i]
-            x_mean = x - rev_f
-            x = x_mean + G[:, None, None] * z
+            if corrector == "langevin":
+                # -- LangevinCorrector.update_fn, sampling.py:232-256
+                alpha = sde.langevin_alpha(vec_t)
+                grad, s1, cg1 = total_grad(x, vec_t)
+                noise = tape["corrector"][i]
+                grad_norm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
+                noise_norm = torch.norm(noise.reshape(B, -1), dim=-1).mean()
+                step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+                x_mean = x + step_size[:, None, None] * grad
+                x = x_mean + torch.sqrt(step_size * 2)[:, None, None] * noise
+                if rec is not None:
+                    rec.update(score_c=s1, cgrad_c=cg1, total_c=grad, grad_norm=grad_norm, noise_norm=noise_norm,
+                               step_size=step_size[0].clone(), x_corr=x.clone())
+            else:
+                assert corrector == "none"
+                x_mean = x
+            if predictor == "reverse_diffusion":
+                # -- ReverseDiffusionPredictor.update_fn, sampling.py:208-213 + sde_lib.py:119-125
+                f, G = sde.discretize(x, vec_t)
+                grad2, s2, cg2 = total_grad(x, vec_t)
+                rev_f = f - G[:, None, None] ** 2 * grad2
+                z = tape["predictor"][i]
+                x_mean = x - rev_f
+                x = x_mean + G[:, None, None] * z
+            elif predictor == "euler_maruyama":
+                # -- EulerMaruyamaPredictor.update_fn, sampling.py:194-200 + sde_lib.py:95-103
+                dt = -1. / sde.N
+                z = tape["predictor"][i]
+                drift, diffusion = sde.sde(x, vec_t)
+                grad2, s2, cg2 = total_grad(x, vec_t)
+                drift = drift - diffusion[:, None, None] ** 2 * grad2 * 1.
+                x_mean = x + drift * dt
+                x = x_mean + diffusion[:, None, None] * math.sqrt(-dt) * z
+            else:
+                assert predictor == "none"
+                grad2 = s2 = cg2 = None
+                x_mean = x
             if rec is not None:
                 rec.update(score_p=s2, cgrad_p=cg2, total_p=grad2, x_mean=x_mean.clone(), x_pred=x.clone())
                 record.append(rec)

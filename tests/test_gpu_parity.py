@@ -441,3 +441,71 @@ def test_full_batch_guided_ofa_step_matches_oracle_on_a_slice():
         close(r["rec_cgrad_c"][0][sl], cg, 2e-5, "cgrad_c")
         close(r["rec_total_c"][0][sl], s + 1000.0 * cg, 2e-5, "total_c")
     assert torch.isfinite(r["rec_x_pred"][0]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# Sampler variants: VESDE (the reference's shipped default), Euler-Maruyama / None predictors,
+# None corrector -- against runs of the reference itself (tests/golden/make_golden_ve.py)
+# ------------------------------------------------------------------------------------------------
+VARIANTS = ["pc_guided_nb201_ve_em_n1000_first8", "pc_uncond_nb201_ve_rd_contractive_n60",
+            "pc_guided_nb201_ve_em_contractive_n60", "pc_uncond_nb201_vp_em_nonecorr_contractive_n60",
+            "pc_uncond_nb201_vp_nonepred_n1000_first6"]
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_pc_sampler_variants_golden(name):
+    g = golden(name)
+    guided = bool(int(g["guided"]))
+    B, S, N = int(g["B"]), int(g["n_run"]), int(g["sde_N"])
+    cfg = score_config(CateDims(), DEV)
+    cfg.sampling["predictor"], cfg.sampling["corrector"] = str(g["predictor"]), str(g["corrector"])
+    model = make_score(CateDims(), int(g["seed"]), preset=str(g["preset"]))
+    sde = sde_lib.VESDE(0.1, 5.0, N) if str(g["sde_kind"]) == "ve" else sde_lib.VPSDE(0.1, 20.0, N)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), float(g["eps"]), conditional=guided)
+    tape = synthetic.noise_tape(S, (B, 8, 7), int(g["tape_seed"]))
+    tape["x0"] = torch.from_numpy(g["x0"])
+    fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
+    fn.max_steps, fn.record = S, True
+    mask = torch.from_numpy(g["mask"])
+    if guided:
+        final = fn(model, mask, make_pred(1), classifier_scale=float(g["classifier_scale"]),
+                   task=synthetic.synthetic_task(10, 20, seed=2))
+    else:
+        final = fn(model, mask.unsqueeze(0))[0]
+    r = fn.last_record
+    first = "first" in name
+    tol_x, tol_s = (5e-6, 1e-5) if first else (2e-4, 2e-4)
+    for i in (range(S) if first else (0, 1, S // 2, S - 1)):
+        if "x_corr" in g:
+            close(r["rec_x_corr"][i], g["x_corr"][i], tol_x, f"x_corr[{i}]")
+            close(r["rec_score_c"][i], g["score_c"][i], tol_s, f"score_c[{i}]")
+        if "score_p" in g:
+            close(r["rec_score_p"][i], g["score_p"][i], tol_s, f"score_p[{i}]")
+            close(r["rec_x_mean"][i], g["x_mean"][i], tol_x, f"x_mean[{i}]")
+            close(r["rec_x_pred"][i], g["x_pred"][i], tol_x, f"x_pred[{i}]")
+        if "cgrad_c" in g:
+            close(r["rec_cgrad_c"][i], g["cgrad_c"][i], 1e-5 if first else 2e-4, f"cgrad_c[{i}]")
+    if "final" in g:
+        close(final, g["final"], 2e-4, "final")
+        q = np.stack(utils.quantize(final))
+        assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
+    elif str(g["predictor"]) == "none":
+        # NonePredictor returns (x, x): the denoised output is the state after the last corrector
+        close(final, (g["x_corr"][S - 1] + 1.0) / 2.0, 5e-6, "final")
+
+
+def test_vesde_philox_prior_scale_and_score_fn_wrapper():
+    """On-device prior of a VESDE is sigma_max * N(0,1); get_score_fn(VESDE) returns the raw model output
+    conditioned on sigma(t) (models/utils.py:106-117)."""
+    from oracle import dnag_oracle as O
+    sd = synthetic.cate_state_dict(CateDims(), seed=4, perturb_norms=True)
+    model = make_score(CateDims(), 4, perturb=True)
+    sde, osde = sde_lib.VESDE(0.1, 5.0, 1000), O.VESDE(0.1, 5.0, 1000)
+    rs = np.random.RandomState(8)
+    B = 9
+    X = torch.from_numpy(rs.standard_normal((B, 8, 7)).astype(np.float32))
+    t = torch.from_numpy(rs.uniform(1e-5, 1, B).astype(np.float32))
+    masks = torch.from_numpy((rs.uniform(0, 1, (B, 8, 8)) < 0.4).astype(np.float32))
+    ref = O.score_fn(sd, osde, X, t, masks)
+    got = mutils.get_score_fn(sde, model, train=False, continuous=True)(X.to(DEV), t.to(DEV), masks.to(DEV))
+    close(got, ref, 5e-6, "VE score")

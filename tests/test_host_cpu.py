@@ -216,6 +216,36 @@ def test_schedule_table_matches_oracle_vpsde():
         sde_lib.VPSDE(0.1, 20, 10).schedule_table(1e-3, 11)
 
 
+def test_schedule_table_vesde_and_euler_maruyama_match_oracle():
+    """VESDE (the reference's shipped default SDE) and the Euler-Maruyama scalars, against the oracle's
+    restatement of sde_lib.py:253-300, :168-177 and sampling.py:194-200."""
+    N = 1000
+    sde, osde = sde_lib.VESDE(0.1, 5.0, N), O.VESDE(0.1, 5.0, N)
+    ts = O.timesteps(osde, 1e-5)
+    tab = sde.schedule_table(1e-5)
+    assert np.array_equal(tab[:, _lib.SCHED_LABEL], osde.marginal_std(ts).numpy())
+    assert np.all(tab[:, _lib.SCHED_ALPHA] == 1.0) and np.all(tab[:, _lib.SCHED_SQRTA] == 1.0)
+    _, G = osde.discretize(torch.zeros(N, 1, 1), ts)
+    assert np.array_equal(tab[:, _lib.SCHED_G], G.numpy()) and np.array_equal(tab[:, _lib.SCHED_G2], (G ** 2).numpy())
+    assert tab[-1, _lib.SCHED_G] == osde.discrete_sigmas[0]                       # k = 0: adjacent sigma is 0
+    assert sde.score_mode == _lib.SCORE_VE and sde.prior_scale == 5.0
+    for s_, o_ in ((sde, osde), (sde_lib.VPSDE(0.1, 20.0, N), O.VPSDE(0.1, 20.0, N))):
+        eps = 1e-5 if s_ is sde else 1e-3
+        tab = s_.schedule_table(eps, predictor="euler_maruyama")
+        ts = O.timesteps(o_, eps)
+        x = torch.ones(N, 1, 1)
+        drift, diffusion = o_.sde(x, ts)
+        dt = -1.0 / N
+        assert np.array_equal(tab[:, _lib.SCHED_SQRTA], drift.reshape(-1).numpy())
+        assert np.array_equal(tab[:, _lib.SCHED_G2], (diffusion ** 2).numpy())
+        assert np.array_equal(tab[:, _lib.SCHED_G], (diffusion[:, None, None] * np.sqrt(-dt)).reshape(-1).numpy())
+        assert np.all(tab[:, _lib.SCHED_DT] == np.float32(dt))
+    torch.manual_seed(0)
+    a = sde.prior_sampling((2, 8, 7))
+    torch.manual_seed(0)
+    assert torch.equal(a, torch.randn(2, 8, 7) * 5.0)
+
+
 def test_registries_and_factory_errors_mirror_the_reference():
     assert sampling.get_predictor("reverse_diffusion") is sampling.ReverseDiffusionPredictor
     assert sampling.get_corrector("langevin") is sampling.LangevinCorrector
@@ -233,12 +263,19 @@ def test_registries_and_factory_errors_mirror_the_reference():
     with pytest.raises(NotImplementedError, match="Sampler name ode unknown"):
         sampling.get_sampling_fn(cfg, sde, (4, 8, 7), inv, 1e-3)
     cfg.sampling["method"] = "pc"
-    cfg.sampling["predictor"] = "euler_maruyama"
+    for pname in ("euler_maruyama", "none", "reverse_diffusion"):        # every registered predictor is built
+        cfg.sampling["predictor"] = pname
+        for s_ in (sde, sde_lib.VESDE(0.1, 5.0, 1000)):
+            assert callable(sampling.get_sampling_fn(cfg, s_, (4, 8, 7), inv, 1e-3))
+    cfg.sampling["probability_flow"] = True
     with pytest.raises(NotImplementedError):
         sampling.get_sampling_fn(cfg, sde, (4, 8, 7), inv, 1e-3)
-    cfg.sampling["predictor"] = "reverse_diffusion"
-    with pytest.raises(NotImplementedError):
-        sampling.get_sampling_fn(cfg, sde_lib.VESDE(), (4, 8, 7), inv, 1e-3)
+    cfg.sampling["probability_flow"] = False
+
+    class SubVP(sde_lib.VPSDE):
+        pass
+    with pytest.raises(NotImplementedError, match="not yet supported"):
+        sampling.get_sampling_fn(cfg, object(), (4, 8, 7), inv, 1e-3)
     fn = sampling.get_sampling_fn(cfg, sde, (4, 8, 7), inv, 1e-3)
     with pytest.raises(RuntimeError, match="MI355X only"):     # no CPU fallback
         fn(mutils.create_model(cfg), utils.nb201_adj().unsqueeze(0))

@@ -174,3 +174,52 @@ def test_pc_guided_ofa(golden, name):
     if "final" in g:
         close(final, g["final"], 0, 2e-4 * np.abs(g["final"]).max())
         assert torch.equal(O.quantize(final.clone()), O.quantize(T(g["final"]).clone()))
+
+
+# ----------------------------------------------------------------------------------------------------
+# Sampler variants: VESDE, Euler-Maruyama / None predictors, None corrector (tests/golden/make_golden_ve.py)
+# ----------------------------------------------------------------------------------------------------
+VARIANTS = ["pc_guided_nb201_ve_em_n1000_first8", "pc_uncond_nb201_ve_rd_contractive_n60",
+            "pc_guided_nb201_ve_em_contractive_n60", "pc_uncond_nb201_vp_em_nonecorr_contractive_n60",
+            "pc_uncond_nb201_vp_nonepred_n1000_first6"]
+
+
+def variant_sde(g, mod):
+    N = int(g["sde_N"])
+    return mod.VESDE(0.1, 5.0, N) if str(g["sde_kind"]) == "ve" else mod.VPSDE(0.1, 20.0, N)
+
+
+def variant_tape(g):
+    B, S = int(g["B"]), int(g["n_run"])
+    tape = synthetic.noise_tape(S, (B, 8, 7), int(g["tape_seed"]))
+    tape["x0"] = T(g["x0"])                       # prior_sampling output (randn * sigma_max for the VESDE)
+    return tape
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_pc_sampler_variants(golden, name):
+    g = golden(name)
+    guided = bool(int(g["guided"]))
+    sd = synthetic.cate_state_dict(CateDims(), seed=int(g["seed"]), preset=str(g["preset"]))
+    kw = {}
+    if guided:
+        sdp = synthetic.predictor_state_dict(PredictorDims(), seed=1)
+        kw = dict(pred_sd=sdp, D_mu=O.set_encode(sdp, synthetic.synthetic_task(10, 20, seed=2)),
+                  classifier_scale=float(g["classifier_scale"]))
+    rec = []
+    S = int(g["n_run"])
+    final = O.pc_sample(sd, variant_sde(g, O), T(g["mask"]), variant_tape(g), eps=float(g["eps"]), snr=float(g["snr"]),
+                        n_steps=S, record=rec, predictor=str(g["predictor"]), corrector=str(g["corrector"]), **kw)
+    for i in sorted({0, 1, S // 2, S - 1}):
+        sc = np.abs(g["x_pred"][i]).max()
+        close(rec[i]["x_pred"], g["x_pred"][i], 0, 2e-4 * sc)
+        close(rec[i]["x_mean"], g["x_mean"][i], 0, 2e-4 * sc)
+        if "score_p" in g:
+            close(rec[i]["score_p"], g["score_p"][i], 0, 2e-4 * np.abs(g["score_p"][i]).max())
+        if "x_corr" in g:
+            close(rec[i]["x_corr"], g["x_corr"][i], 0, 2e-4 * sc)
+        if "cgrad_c" in g:
+            close(rec[i]["cgrad_c"], g["cgrad_c"][i], 0, 1e-3 * np.abs(g["cgrad_c"][i]).max())
+    if "final" in g:
+        close(final, g["final"], 0, 2e-4 * np.abs(g["final"]).max())
+        assert torch.equal(O.quantize(final.clone()), O.quantize(T(g["final"]).clone()))
