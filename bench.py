@@ -32,6 +32,12 @@ from diffusionnag_amd.specs import CateDims, PredictorCateDims, PredictorDims  #
 # algorithmic FLOPs (2 per MAC) of one guided sample (2000 score evaluations + guidance gradients): SURVEY.md section 8d
 FLOP_PER_SAMPLE = {"nb201": 136.3e9, "ofa": 345.4e9}
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# Fabric-side bytes of ONE launch of the dominant kernel (final.linears.1 at B=4096, NB201) from PMC counters:
+# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as the guide's HBM
+# section prescribes for gfx950 (profiles/r01c_pmc_traffic.json: 1.238 GB read + 0.201 GB written; algorithmic
+# bytes 0.412 GB -- the excess is the 9.4 MB weight matrix re-read from the Infinity Cache by every row panel).
+# Counters cannot be collected inside this process, so the figure is quoted only for the shape it was measured on.
+PMC_TRAFFIC_BYTES = {("nb201", 4096): 1439538758}
 
 
 class Cfg(dict):
@@ -185,9 +191,10 @@ def main():
                                     "Philox noise on device"),
                        "batch_per_gpu": B, "global_batch": total, "pc_steps": a.sde_steps,
                        "score_evals_per_sample": 2 * a.sde_steps, "parallelism": f"batch-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bias_act_kernel<true,1> (final.linears.1, M x 1536 x 1536, fp32 MFMA)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_bias_act_kernel<1,1> (final.linears.1, M x 1536 x 1536, fp32 MFMA)",
                          "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": PMC_TRAFFIC_BYTES.get((a.workload, B)),
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01c_pmc_traffic.json)",
                          "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value},
             "whole_path_tflops": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world,
             "whole_path_frac_of_f32_mfma_peak": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
