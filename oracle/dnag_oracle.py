@@ -202,8 +202,30 @@ def time_mlp(sd: SD, labels: Tensor, d_model: int) -> Tensor:
     return _lin(sd, "timeEmb2", F.silu(_lin(sd, "timeEmb1", e)))
 
 
+def _drop(x: Tensor, dropout: Optional[dict], key: str) -> Tensor:
+    """nn.Dropout in training mode with an injected keep mask: x * keep / (1 - p).  ``dropout`` is
+    ``{'p': p, 'masks': {site: keep}}``; None (or p = 0) is the identity (eval mode)."""
+    if dropout is None or dropout["p"] == 0.0:
+        return x
+    return x * dropout["masks"][key] / (1.0 - dropout["p"])
+
+
+def dropout_sites(B: int, N: int, d: int = 64, n_head: int = 8, d_ff: int = 128, n_layers: int = 12) -> "OrderedDict":
+    """Dropout sites of CATE in the order the reference's forward reaches them, with their shapes:
+    cate.py:147 (dropout_op), then per layer transformer.py:19 (attention probabilities), :80
+    (SelfAttentionBlock), :54 (FFN hidden), :108 (FeedForwardBlock)."""
+    from collections import OrderedDict
+    sites = OrderedDict(emb=(B, N, d))
+    for l in range(n_layers):
+        sites[f"attn{l}"] = (B, n_head, N, N)
+        sites[f"sa{l}"] = (B, N, d)
+        sites[f"ffh{l}"] = (B, N, d_ff)
+        sites[f"ffo{l}"] = (B, N, d)
+    return sites
+
+
 def encoder_stack(sd: SD, prefix: str, emb: Tensor, mask: Tensor, n_layers: int, n_head: int,
-                  record: Optional[dict] = None) -> List[Tensor]:
+                  record: Optional[dict] = None, dropout: Optional[dict] = None) -> List[Tensor]:
     """transformer.py:166-179 (Encoder), :127-136 (EncoderBlock), :69-80, :23-42, :12-20, :97-108."""
     B, N, d = emb.shape
     dk = d // n_head
@@ -220,11 +242,12 @@ def encoder_stack(sd: SD, prefix: str, emb: Tensor, mask: Tensor, n_layers: int,
         a = F.softmax(s, dim=-1)                                                # :17
         if record is not None and l == 0:
             record["attn0"] = a
+        a = _drop(a, dropout, f"attn{l}")                                       # :19
         o = torch.matmul(a, v).transpose(1, 2).contiguous().view(B, -1, d)      # :20, :41
-        x = _lin(sd, p + ".self_attn.attn.linears.3", o) + x                    # :42, :80
+        x = _drop(_lin(sd, p + ".self_attn.attn.linears.3", o), dropout, f"sa{l}") + x      # :42, :80
         u = _ln(sd, p + ".feed_forward.norm", x)                                # :106
-        x = _lin(sd, p + ".feed_forward.feed_forward.w_2",
-                 F.relu(_lin(sd, p + ".feed_forward.feed_forward.w_1", u))) + x  # :54, :108
+        hid = _drop(F.relu(_lin(sd, p + ".feed_forward.feed_forward.w_1", u)), dropout, f"ffh{l}")   # :54
+        x = _drop(_lin(sd, p + ".feed_forward.feed_forward.w_2", hid), dropout, f"ffo{l}") + x       # :54, :108
         outs.append(_ln(sd, f"{prefix}.norms.{l}", x))                          # :177
     return outs
 
@@ -237,13 +260,15 @@ def mlp_head(sd: SD, prefix: str, h: Tensor, n_lin: int) -> Tensor:
 
 
 def cate_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, *, n_layers: int = 12,
-                 n_head: int = 8, stagewise_pos: bool = False, record: Optional[dict] = None) -> Tensor:
-    """CATE.forward, cate.py:145-164 (eval mode: dropouts are identity, models/utils.py:63-65)."""
+                 n_head: int = 8, stagewise_pos: bool = False, record: Optional[dict] = None,
+                 dropout: Optional[dict] = None) -> Tensor:
+    """CATE.forward, cate.py:145-164.  ``dropout=None``: eval mode (dropouts are identity,
+    models/utils.py:63-65); otherwise training mode with injected keep masks (``_drop``)."""
     d = sd["opEmb.fc.weight"].shape[0]
-    emb_x = _lin(sd, "opEmb.fc", X) * math.sqrt(d)                              # transformer.py:230
+    emb_x = _drop(_lin(sd, "opEmb.fc", X) * math.sqrt(d), dropout, "emb")       # transformer.py:230, cate.py:147
     emb_x = emb_x + positional_table(X.shape[1], d, stagewise_pos)[: X.shape[1]]  # cate.py:149-151
     emb = emb_x + time_mlp(sd, time_cond, d).unsqueeze(1)                       # cate.py:155-159
-    hs = encoder_stack(sd, "graph_encoder.encoder_f", emb, maskX, n_layers, n_head, record)
+    hs = encoder_stack(sd, "graph_encoder.encoder_f", emb, maskX, n_layers, n_head, record, dropout)
     h = torch.cat(hs, dim=-1)                                                   # cate.py:85
     if record is not None:
         record["concat"] = h
@@ -258,6 +283,41 @@ def score_fn(sd: SD, sde, x: Tensor, t: Tensor, maskX: Tensor, **kw) -> Tensor:
     out = cate_forward(sd, x, t * 999, maskX, **kw)
     std = sde.marginal_std(t)
     return -out / std[:, None, None]
+
+
+# ----------------------------------------------------------------------------------------------
+# Denoising score matching loss and its parameter gradients (losses.py:110-168, :204-235)
+# ----------------------------------------------------------------------------------------------
+
+def dsm_loss(sd: SD, sde, x: Tensor, t: Tensor, z: Tensor, maskX: Tensor, *, reduce_mean: bool = True,
+             dropout: Optional[dict] = None, **kw) -> Tensor:
+    """get_sde_loss_fn_nas.loss_fn (losses.py:127-166) with likelihood_weighting=False and the random
+    draws ``t`` (:139) and ``z`` (:141) injected.  VPSDE: mean = exp(lmc) x, std (sde_lib.py:179-188);
+    VESDE: mean = x, std = sigma(t) (:279-282)."""
+    if isinstance(sde, VESDE):
+        mean, std = x, sde.marginal_std(t)
+        labels = std
+    else:
+        lmc = -0.25 * t ** 2 * (sde.beta_1 - sde.beta_0) - 0.5 * t * sde.beta_0
+        mean, std = torch.exp(lmc[:, None, None]) * x, torch.sqrt(1.0 - torch.exp(2.0 * lmc))
+        labels = t * 999
+    perturbed = mean + std[:, None, None] * z                                   # :145
+    out = cate_forward(sd, perturbed, labels, maskX, dropout=dropout, **kw)
+    score = out if isinstance(sde, VESDE) else -out / std[:, None, None]        # models/utils.py:103 / :116
+    losses = torch.square(score * std[:, None, None] + z)                       # :149
+    losses = losses.reshape(losses.shape[0], -1)
+    losses = torch.mean(losses, dim=-1) if reduce_mean else 0.5 * torch.sum(losses, dim=-1)   # :151-154
+    return losses.mean()                                                        # :155
+
+
+def dsm_loss_and_grads(sd: SD, sde, x: Tensor, t: Tensor, z: Tensor, maskX: Tensor, **kw):
+    """step_fn's ``loss.backward()`` (losses.py:222-223): the loss and d loss / d parameter for every
+    entry of the state_dict (insertion order)."""
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    with torch.enable_grad():
+        loss = dsm_loss(leaves, sde, x, t, z, maskX, **kw)
+        grads = torch.autograd.grad(loss, list(leaves.values()))
+    return loss.detach(), {k: g for k, g in zip(leaves.keys(), grads)}
 
 
 # ----------------------------------------------------------------------------------------------

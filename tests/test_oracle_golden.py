@@ -223,3 +223,45 @@ def test_pc_sampler_variants(golden, name):
     if "final" in g:
         close(final, g["final"], 0, 2e-4 * np.abs(g["final"]).max())
         assert torch.equal(O.quantize(final.clone()), O.quantize(T(g["final"]).clone()))
+
+
+# ----------------------------------------------------------------------------------------------------
+# DSM training step: loss and parameter gradients (tests/golden/make_golden_train.py)
+# ----------------------------------------------------------------------------------------------------
+def train_case(g):
+    """Inputs of a training golden, regenerated from its seeds exactly as make_golden_train.py drew them."""
+    B, p = int(g["B"]), float(g["p"])
+    rs = np.random.RandomState(int(g["input_seed"]))
+    ops = rs.randint(0, 7, size=(B, 8))
+    x = np.zeros((B, 8, 7), np.float32)
+    x[np.arange(B)[:, None], np.arange(8)[None, :], ops] = 1.0
+    x = 2.0 * x - 1.0
+    u = rs.uniform(0, 1, size=B).astype(np.float32)
+    z = rs.standard_normal((B, 8, 7)).astype(np.float32)
+    eps = float(g["eps"])
+    t = T(u) * (1 - eps) + eps                                      # losses.py:139
+    dropout = None
+    if p > 0:
+        rs = np.random.RandomState(int(g["mask_seed"]))
+        dropout = {"p": p, "masks": {k: T((rs.uniform(0, 1, size=shape) >= p).astype(np.float32))
+                                     for k, shape in O.dropout_sites(B, 8).items()}}
+    return T(x), t, T(z), dropout
+
+
+@pytest.mark.parametrize("name", ["train_nb201_vp_nodrop", "train_nb201_vp_drop", "train_nb201_ve_drop"])
+def test_dsm_loss_and_parameter_gradients(golden, name):
+    g = golden(name)
+    x, t, z, dropout = train_case(g)
+    sd = synthetic.cate_state_dict(CateDims(), seed=0, perturb_norms=True)
+    sde = O.VPSDE(0.1, 20.0, 1000) if str(g["sde_kind"]) == "vp" else O.VESDE(0.1, 5.0, 1000)
+    maskB = T(g["mask"]).unsqueeze(0).repeat(x.shape[0], 1, 1)
+    loss, grads = O.dsm_loss_and_grads(sd, sde, x, t, z, maskB, dropout=dropout)
+    close(loss, g["loss"], 1e-5, 0)
+    names = list(sd.keys())
+    norms = np.array([float(grads[k].double().norm()) for k in names])
+    close(norms, g["grad_norms"], 1e-4, 1e-7)
+    for key in g:
+        if key.startswith("grad:"):
+            k = key[5:]
+            got = grads[k[:-4]][:8] if k.endswith("[:8]") else grads[k]
+            close(got, g[key], 0, 2e-5 * np.abs(g[key]).max() + 1e-9)
