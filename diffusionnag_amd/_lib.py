@@ -30,6 +30,7 @@ EXPORTS = (
     "dnag_predcate_workspace_bytes", "dnag_workspace_bytes", "dnag_workspace_bytes_predcate",
     "dnag_cate_forward", "dnag_pred_forward_grad", "dnag_predcate_forward_grad", "dnag_pc_sample",
     "dnag_quantize", "dnag_timing_begin", "dnag_timing_read", "dnag_timing_end",
+    "dnag_train_workspace_bytes", "dnag_dropout_mask_bytes", "dnag_dropout_fill", "dnag_cate_dsm_step",
 )
 
 
@@ -66,6 +67,16 @@ class PcArgsC(C.Structure):
         ("rec_score_c", _fp), ("rec_total_c", _fp), ("rec_x_corr", _fp), ("rec_score_p", _fp),
         ("rec_total_p", _fp), ("rec_x_mean", _fp), ("rec_x_pred", _fp),
         ("rec_cgrad_c", _fp), ("rec_cgrad_p", _fp), ("rec_step_size", _fp),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
+class TrainArgsC(C.Structure):
+    _fields_ = [
+        ("cate_dims", C.POINTER(CateDimsC)), ("params", _fp), ("tables", _fp), ("batch", C.c_int32),
+        ("x", _fp), ("z", _fp), ("mean_coef", _fp), ("std", _fp), ("labels", _fp), ("mask", _fp),
+        ("mask_stride", C.c_int32), ("score_mode", C.c_int32), ("reduce_mean", C.c_int32),
+        ("keep", C.c_void_p), ("dropout_p", C.c_float), ("loss", _fp), ("grads", _fp),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
     ]
 
@@ -123,6 +134,14 @@ def load() -> C.CDLL:
     lib.dnag_timing_read.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dnag_timing_end.restype = i32
     lib.dnag_timing_end.argtypes = []
+    lib.dnag_train_workspace_bytes.restype = sz
+    lib.dnag_train_workspace_bytes.argtypes = [C.POINTER(CateDimsC), i32]
+    lib.dnag_dropout_mask_bytes.restype = sz
+    lib.dnag_dropout_mask_bytes.argtypes = [C.POINTER(CateDimsC), i32]
+    lib.dnag_dropout_fill.restype = i32
+    lib.dnag_dropout_fill.argtypes = [C.POINTER(CateDimsC), i32, C.c_float, C.c_uint64, vp, vp]
+    lib.dnag_cate_dsm_step.restype = i32
+    lib.dnag_cate_dsm_step.argtypes = [C.POINTER(TrainArgsC)]
     if lib.dnag_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.dnag_abi_version()} != 1; rebuild the library")
     _lib = lib

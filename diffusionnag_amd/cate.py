@@ -122,6 +122,12 @@ class CATE(PackedModule):
         self.has_pos = 'pos_enc_type' in config.model
         if not self.has_pos:
             raise NotImplementedError("CATE without positional encoding is not built")
+        # dropout rates of the training-mode forward (cate.py:114, transformer.py:32-103); the training
+        # kernels take one rate for every site, as every shipped config has (configs/tr_scorenet.py:92, :100)
+        self.dropout_p = float(config.model.dropout) if 'dropout' in config.model else 0.0
+        ge_p = float(ge.dropout) if 'dropout' in ge else self.dropout_p
+        if ge_p != self.dropout_p:
+            raise NotImplementedError("model.dropout and model.graph_encoder.dropout must be equal on the HIP path")
         build_parameters(self, cate_param_spec(self.dims))
         self._ws = Workspace()
 
@@ -147,7 +153,8 @@ class CATE(PackedModule):
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, X, time_cond, maskX, *, return_concat=False, return_attn0=False):
         if self.training:
-            raise NotImplementedError("CATE.forward on the HIP path is eval-only (dropout is a training-step row)")
+            raise NotImplementedError("CATE.forward on the HIP path is eval-only; the training-mode forward lives in the "
+                                      "fused DSM step (diffusionnag_amd.losses.get_sde_loss_fn_nas)")
         lib = _lib.load()
         dev = _lib.require_device(X, time_cond, maskX)
         B, N, V = X.shape

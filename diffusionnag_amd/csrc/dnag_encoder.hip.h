@@ -188,14 +188,28 @@ struct EncSave {
     size_t rows;
 };
 
+// Dropout keep masks of a training-mode forward (models/cate.py:147, transformer.py:19, :54, :80, :108):
+// one byte per site element, 1 = keep.  Layout, rows = batch*N, row = graph*N + node:
+//   emb [rows][64], then per layer l a slab [rows][per_layer] with per_layer = H*N + 64 + DFF + 64 and
+//   a row holding  attention probabilities [H][N] (keys of this query) | self-attention block output
+//   [64] | FFN hidden [DFF] | FFN output [64].
+// A dropped value is 0, a kept one v / keep_prob (keep_prob = 1 - p), as nn.Dropout computes it.
+struct DropMasks {
+    const uint8_t *keep;   // null: dropout off
+    float keep_prob;
+    size_t rows;
+    int per_layer;
+};
+__device__ __forceinline__ float drop_apply(float v, uint8_t keep, float keep_prob) { return __fdiv_rn(v * (float)keep, keep_prob); }
+
 // x [batch][N][V]; temb [tstride ? batch : 1][64]; mask [mstride ? batch : 1][N][N];
 // concat [rows_pad][L*64] (row = graph*N + node); attn0 [batch][H][N][N] or null.
-template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false>
+template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict__ P, const CateLayout lay,
                                                          const float *__restrict__ x, const float *__restrict__ temb,
                                                          int tstride, const float *__restrict__ mask, int mstride,
                                                          float *__restrict__ concat, float *__restrict__ attn0, int batch,
-                                                         int dbg_skip, const EncSave sv) {
+                                                         int dbg_skip, const EncSave sv, const DropMasks dm) {
     typedef EncGeom<N, G, DFF> Ge;
     constexpr int R = Ge::R, MT = Ge::MT, RP = Ge::RP, HS = Ge::HS, QS = Ge::QS;
     constexpr int D = DNAG_D, DK = D / H;
@@ -254,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
 #pragma unroll
                     for (int v = 0; v < V; ++v) acc = fmaf(xin[r * V + v], We[c * V + v], acc);
                     val = (acc + be[c]) * 8.0f;
+                    if constexpr (DROP) val = drop_apply(val, dm.keep[((size_t)g0 * N + r) * D + c], dm.keep_prob);   // cate.py:147
                     if (WITH_PE) val = val + pe[n * D + c];
                     val = val + temb[(size_t)(tstride ? g0 + g : 0) * D + c];
                 }
@@ -269,6 +284,9 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
 
     for (int l = 0; l < L; ++l) {
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
+        // keep masks of this layer's sites for local row lr (DROP only; dead rows never read them)
+        const uint8_t *KL = nullptr;
+        if constexpr (DROP) KL = dm.keep + dm.rows * D + ((size_t)l * dm.rows + (size_t)g0 * N) * dm.per_layer;
         // ---- QKV = LN1(h) Wqkv'^T + bqkv' --------------------------------------------------------
         if (!(dbg_skip & 1)) {
             const float *W = LP + lay.l_wqkv, *bias = LP + lay.l_bqkv;
@@ -320,9 +338,10 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
             for (int e = 0; e < DK; ++e) o[e] = 0.f;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                const float p = s[j] / den;
+                float p = s[j] / den;
                 if (attn0 != nullptr && l == 0 && g0 + g < batch)
                     attn0[(((size_t)(g0 + g) * H + hd) * N + i) * N + j] = p;
+                if constexpr (DROP) if (g0 + g < batch) p = drop_apply(p, KL[(size_t)row * dm.per_layer + hd * N + j], dm.keep_prob);   // transformer.py:19
                 const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK;
 #pragma unroll
                 for (int e = 0; e < DK; e += 4) {
@@ -349,7 +368,9 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     for (int i = 0; i < 16; ++i) {
                         const int lr = mt * 32 + acc_row(i, h);
                         float *hp = hbuf + lr * HS + col;
-                        const float hv = (acc[i] + bv) + *hp;
+                        float yv = acc[i] + bv;
+                        if constexpr (DROP) if (live(lr)) yv = drop_apply(yv, KL[(size_t)lr * dm.per_layer + H * N + col], dm.keep_prob);   // transformer.py:80
+                        const float hv = yv + *hp;
                         *hp = hv;
                         if constexpr (SAVE) if (live(lr)) sv.h1[((size_t)l * sv.rows + (size_t)g0 * N + lr) * D + col] = hv;
                     }
@@ -373,7 +394,8 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         const int lr = mt * 32 + acc_row(i, h);
-                        const float fv = fmaxf(acc[i] + bv, 0.f);
+                        float fv = fmaxf(acc[i] + bv, 0.f);
+                        if constexpr (DROP) if (live(lr)) fv = drop_apply(fv, KL[(size_t)lr * dm.per_layer + H * N + D + col], dm.keep_prob);   // transformer.py:54
                         qkv[lr * QS + col] = fv;
                         if constexpr (SAVE) if (live(lr)) sv.f[((size_t)l * sv.rows + (size_t)g0 * N + lr) * DFF + col] = fv;
                     }
@@ -394,7 +416,9 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     for (int i = 0; i < 16; ++i) {
                         const int lr = mt * 32 + acc_row(i, h);
                         float *hp = hbuf + lr * HS + col;
-                        const float hv = (acc[i] + bv) + *hp;
+                        float yv = acc[i] + bv;
+                        if constexpr (DROP) if (live(lr)) yv = drop_apply(yv, KL[(size_t)lr * dm.per_layer + H * N + D + DFF + col], dm.keep_prob);   // transformer.py:108
+                        const float hv = yv + *hp;
                         *hp = hv;
                         if constexpr (SAVE) if (live(lr)) sv.h[((size_t)(l + 1) * sv.rows + (size_t)g0 * N + lr) * D + col] = hv;
                     }

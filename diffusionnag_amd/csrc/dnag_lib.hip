@@ -15,6 +15,7 @@
 #include "dnag_head.hip.h"
 #include "dnag_predictor.hip.h"
 #include "dnag_predcate.hip.h"
+#include "dnag_train.hip.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -486,7 +487,9 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
     const int grid = (batch + G - 1) / G;
     EncSave none;
     memset(&none, 0, sizeof(none));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch, env_int("DNAG_ENC_SKIP"), none);
+    DropMasks nodrop;
+    memset(&nodrop, 0, sizeof(nodrop));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch, env_int("DNAG_ENC_SKIP"), none, nodrop);
     LAUNCH_CHECK();
     return 0;
 }
@@ -607,8 +610,10 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_set = true;
         }
+        DropMasks nodrop;
+        memset(&nodrop, 0, sizeof(nodrop));
         hipLaunchKernelGGL(kern, dim3((batch + PC_G - 1) / PC_G), dim3(256), lds, st, P, e, x, temb, tstride, mask, mstride,
-                           ws + w.concat, (float *)nullptr, batch, 0, sv);
+                           ws + w.concat, (float *)nullptr, batch, 0, sv, nodrop);
         LAUNCH_CHECK();
     }
     // final MLP (cate.py:323), flatten, regeress MLP (:325-326), pred_fc (:348)
@@ -798,6 +803,247 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     LAUNCH_CHECK();
     if (p->x_last) HIP_TRY(hipMemcpyAsync(p->x_last, x, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (p->x_mean_last) HIP_TRY(hipMemcpyAsync(p->x_mean_last, x_mean, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// DSM training step
+// ---------------------------------------------------------------------------------------------
+struct TrainWs {
+    size_t rows, rows_pad;
+    int nblk_enc, nz_rows, nz_b;
+    size_t packed, temb, save_e, save_pre, dpre, dtau, xt, concat, h1, h2, out, dout, dh2, dh1, dconcat, T1, T2;
+    size_t sv_h, sv_h1, sv_qkv, sv_f, part, gsum, scratch, lossp, total;
+};
+#define TRAIN_G 8
+#define TRAIN_LOSS_BLOCKS 128
+
+static TrainWs train_ws(const dnag_cate_dims &c, int batch) {
+    TrainWs w;
+    const TrainLayout tl = train_layout(c);
+    const GradLayout gl = grad_layout(c);
+    const size_t N = c.max_node, V = c.n_vocab, d = c.d_model, dff = c.d_ff, L = c.n_layers, F = tl.enc.F, Hd = tl.enc.Hd;
+    w.rows = (size_t)batch * N;
+    w.rows_pad = up(w.rows, GEMM_BM);
+    w.nblk_enc = (batch + TRAIN_G - 1) / TRAIN_G;
+    w.nz_rows = (int)((w.rows + 127) / 128 < 64 ? (w.rows + 127) / 128 : 64);
+    w.nz_b = (batch + 15) / 16 < 64 ? (batch + 15) / 16 : 64;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += up(n, 64); return at; };
+    w.packed = take(tl.total);
+    w.temb = take((size_t)batch * d);
+    w.save_e = take((size_t)batch * d);
+    w.save_pre = take((size_t)batch * 4 * d);
+    w.dpre = take((size_t)batch * 4 * d);
+    w.dtau = take((size_t)batch * d);
+    w.xt = take(w.rows * V);
+    w.concat = take(w.rows_pad * F);
+    w.h1 = take(w.rows_pad * Hd);
+    w.h2 = take(w.rows_pad * Hd);
+    w.out = take(w.rows_pad * V);
+    w.dout = take(w.rows_pad * V);
+    w.dh2 = take(w.rows_pad * Hd);
+    w.dh1 = take(w.rows_pad * Hd);
+    w.dconcat = take(w.rows_pad * F);
+    w.T1 = take(Hd * w.rows_pad);
+    w.T2 = take(Hd * w.rows_pad);
+    w.sv_h = take((L + 1) * w.rows_pad * d);
+    w.sv_h1 = take(L * w.rows_pad * d);
+    w.sv_qkv = take(L * w.rows_pad * 3 * d);
+    w.sv_f = take(L * w.rows_pad * dff);
+    w.part = take((size_t)w.nblk_enc * gl.total);
+    w.gsum = take(gl.total);
+    const size_t big = (V * Hd > 4 * d * d ? V * Hd : 4 * d * d);
+    w.scratch = take(64 * big);
+    w.lossp = take(TRAIN_LOSS_BLOCKS);
+    w.total = o;
+    return w;
+}
+
+static int check_train_dims(const dnag_cate_dims *d) {
+    if (int rc = check_cate(d)) return rc;
+    if (!is_nb201(*d)) return fail(DNAG_E_ARG, "the training step is built for NAS-Bench-201 graphs (8x7) only");
+    return 0;
+}
+
+extern "C" size_t dnag_train_workspace_bytes(const dnag_cate_dims *d, int batch) {
+    if (!d || batch < 1) return 0;
+    return train_ws(*d, batch).total * sizeof(float);
+}
+extern "C" size_t dnag_dropout_mask_bytes(const dnag_cate_dims *d, int batch) {
+    if (!d || batch < 1) return 0;
+    const size_t rows = (size_t)batch * d->max_node;
+    const size_t per_layer = (size_t)d->n_head * d->max_node + 2 * (size_t)d->d_model + d->d_ff;
+    return rows * d->d_model + (size_t)d->n_layers * rows * per_layer;
+}
+extern "C" int dnag_dropout_fill(const dnag_cate_dims *d, int batch, float p, uint64_t seed, uint8_t *keep, void *stream) {
+    if (int rc = check_cate(d)) return rc;
+    if (!keep || batch < 1 || !(p >= 0.f && p < 1.f)) return fail(DNAG_E_ARG, "bad dropout arguments");
+    const size_t n = dnag_dropout_mask_bytes(d, batch);
+    hipLaunchKernelGGL(dropout_fill_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, keep, n, p, seed);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+// out[I][J] (row stride J, scaled) = sum over rows of fa(A[r][i]) fb(B[r][j]) via row chunks + ordered reduction
+template <int ACTB>
+static int launch_tn_small(const float *A, int lda, const float *Bm, int ldb, size_t rows, int nz, int I, int J, float *scratch,
+                           float *out, hipStream_t st) {
+    const int chunk = (int)((rows + nz - 1) / nz);
+    hipLaunchKernelGGL((tn_small_kernel<ACTB>), dim3((I * J + 255) / 256, 1, nz), dim3(256), 0, st, A, lda, Bm, ldb, (int)rows, chunk, I, J, scratch);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, scratch, nz, (size_t)I * J, (size_t)I * J, out, 1.0f);
+    LAUNCH_CHECK();
+    return 0;
+}
+static int launch_colsum(const float *A, int lda, size_t rows, int nz, int J, float *scratch, float *out, hipStream_t st) {
+    const int chunk = (int)((rows + nz - 1) / nz);
+    hipLaunchKernelGGL(colsum_kernel, dim3((J + 255) / 256, 1, nz), dim3(256), 0, st, A, lda, (int)rows, chunk, J, scratch);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((J + 255) / 256), dim3(256), 0, st, scratch, nz, (size_t)J, (size_t)J, out, 1.0f);
+    LAUNCH_CHECK();
+    return 0;
+}
+static int launch_transpose(const float *in, size_t rows, int cols, int ld_in, float *out, size_t rows_out, size_t ld_out, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (unsigned)((rows_out + 31) / 32)), dim3(256), 0, st, in, (int)rows, cols, ld_in, out,
+                       (int)rows_out, (int)ld_out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
+    if (!p) return fail(DNAG_E_ARG, "args is NULL");
+    if (int rc = check_train_dims(p->cate_dims)) return rc;
+    if (!p->params || !p->tables || !p->x || !p->z || !p->mean_coef || !p->std || !p->labels || !p->mask || !p->loss || !p->workspace)
+        return fail(DNAG_E_ARG, "NULL pointer");
+    if (p->batch < 1) return fail(DNAG_E_ARG, "batch=%d", p->batch);
+    if (p->score_mode != DNAG_SCORE_VP && p->score_mode != DNAG_SCORE_VE) return fail(DNAG_E_ARG, "score_mode=%d", p->score_mode);
+    if (!(p->dropout_p >= 0.f && p->dropout_p < 1.f)) return fail(DNAG_E_ARG, "dropout_p=%g", p->dropout_p);
+    const dnag_cate_dims &cd = *p->cate_dims;
+    const CateStateLayout sl = cate_state_layout(cd);
+    const TrainLayout tl = train_layout(cd);
+    const CateLayout &e = tl.enc;
+    const GradLayout gl = grad_layout(cd);
+    const TrainWs w = train_ws(cd, p->batch);
+    if (p->workspace_bytes < w.total * sizeof(float))
+        return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", p->workspace_bytes, w.total * sizeof(float));
+    hipStream_t st = (hipStream_t)p->stream;
+    float *ws = (float *)p->workspace;
+    const float *S = p->params;
+    float *P = ws + w.packed;
+    const int B = p->batch, N = cd.max_node, V = cd.n_vocab, d = e.d, dff = e.dff, L = e.L, F = e.F, Hd = e.Hd;
+    const size_t rows = w.rows, rows_pad = w.rows_pad;
+    const bool drop = p->keep != nullptr && p->dropout_p > 0.f;
+    auto cpy = [&](size_t dst, const float *src, size_t n) { return hipMemcpyAsync(P + dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st); };
+
+    // ---- 0. pack: state order -> kernel layouts (forward + transposed backward operands) -------------------
+    HIP_TRY(cpy(e.emb_w, S + sl.emb_w, (size_t)d * V));
+    HIP_TRY(cpy(e.emb_b, S + sl.emb_b, (size_t)d + 4 * d * d + 4 * d + 4 * d * d + d));      // emb_b, timeEmb1, timeEmb2
+    HIP_TRY(cpy(e.f0_w, S + sl.f0_w, (size_t)Hd * F + Hd + (size_t)Hd * Hd + Hd));             // final.linears.0, .1
+    HIP_TRY(cpy(e.f2_w, S + sl.f2_w, (size_t)V * Hd));
+    HIP_TRY(cpy(e.f2_b, S + sl.f2_b, (size_t)V));
+    HIP_TRY(cpy(e.pe, p->tables, (size_t)N * d));
+    HIP_TRY(cpy(e.freq, p->tables + (size_t)N * d, (size_t)d / 2));
+    hipLaunchKernelGGL(train_pack_layers_kernel, dim3(32, L), dim3(256), 0, st, S, sl, P, tl);
+    LAUNCH_CHECK();
+    if (p->grads) {
+        if (int rc = launch_transpose(S + sl.f0_w, Hd, F, F, P + tl.f0T, Hd, Hd, st)) return rc;      // [Hd][F] -> [F][Hd]
+        if (int rc = launch_transpose(S + sl.f1_w, Hd, Hd, Hd, P + tl.f1T, Hd, Hd, st)) return rc;
+    }
+    // ---- 1. time embedding per graph, perturbation -----------------------------------------------------------
+    hipLaunchKernelGGL(time_embed_train_kernel, dim3(B), dim3(256), (size_t)5 * d * sizeof(float), st, p->labels, d, P + e.freq, P + e.t1_w,
+                       P + e.t1_b, P + e.t2_w, P + e.t2_b, ws + w.temb, ws + w.save_e, ws + w.save_pre);
+    LAUNCH_CHECK();
+    const size_t nelem = rows * V;
+    hipLaunchKernelGGL(perturb_kernel, dim3(512), dim3(256), 0, st, p->x, p->z, p->mean_coef, p->std, ws + w.xt, nelem, N * V);
+    LAUNCH_CHECK();
+    if (rows_pad > rows) HIP_TRY(hipMemsetAsync(ws + w.concat + rows * F, 0, (rows_pad - rows) * F * sizeof(float), st));
+    // ---- 2. encoder forward, saving the activations the backward pass needs -------------------------------------
+    EncSave sv;
+    sv.h = ws + w.sv_h; sv.h1 = ws + w.sv_h1; sv.qkv = ws + w.sv_qkv; sv.f = ws + w.sv_f; sv.rows = rows_pad;
+    DropMasks dm;
+    memset(&dm, 0, sizeof(dm));
+    if (drop) { dm.keep = p->keep; dm.keep_prob = 1.0f - p->dropout_p; dm.rows = rows; dm.per_layer = cd.n_head * N + 2 * d + dff; }
+    {
+        typedef EncGeom<8, TRAIN_G, 128> Ge;
+        const size_t lds = Ge::lds_floats * sizeof(float);
+        auto k_drop = encoder_kernel<8, 7, TRAIN_G, 8, 128, true, true, true>;
+        auto k_nodrop = encoder_kernel<8, 7, TRAIN_G, 8, 128, true, true, false>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_drop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nodrop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(drop ? k_drop : k_nodrop, dim3(w.nblk_enc), dim3(256), lds, st, P, e, ws + w.xt, ws + w.temb, 1, p->mask,
+                           p->mask_stride ? 1 : 0, ws + w.concat, (float *)nullptr, B, 0, sv, dm);
+        LAUNCH_CHECK();
+    }
+    // ---- 3. head MLP and loss ------------------------------------------------------------------------------------
+    if (int rc = launch_gemm_t<ACT_ELU, 3>(ws + w.concat, P + e.f0_w, P + e.f0_b, ws + w.h1, nullptr, rows_pad, Hd, F, F, Hd, Hd, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_ELU, 3>(ws + w.h1, P + e.f1_w, P + e.f1_b, ws + w.h2, nullptr, rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    {
+        ExitArgs a;
+        memset(&a, 0, sizeof(a));
+        a.mode = EXIT_FORWARD; a.batch = B; a.out = ws + w.out;
+        if (int rc = launch_exit(cd, e, P, ws + w.h2, a, st)) return rc;
+    }
+    hipLaunchKernelGGL(dsm_loss_kernel, dim3(TRAIN_LOSS_BLOCKS), dim3(256), 0, st, ws + w.out, p->z, p->std, p->score_mode, p->reduce_mean ? 1 : 0, B,
+                       N * V, rows_pad * V, ws + w.dout, ws + w.lossp);
+    LAUNCH_CHECK();
+    {
+        const float scale = p->reduce_mean ? 1.0f / ((float)(N * V) * (float)B) : 0.5f / (float)B;
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(256), 0, st, ws + w.lossp, TRAIN_LOSS_BLOCKS, (size_t)1, (size_t)1, p->loss, scale);
+        LAUNCH_CHECK();
+    }
+    if (!p->grads) return 0;
+    float *G = p->grads;
+    float *scr = ws + w.scratch;
+    // ---- 4. head backward ------------------------------------------------------------------------------------------
+    if (int rc = launch_tn_small<0>(ws + w.dout, V, ws + w.h2, Hd, rows, w.nz_rows, V, Hd, scr, G + sl.f2_w, st)) return rc;     // dW3 = dout^T H2
+    if (int rc = launch_colsum(ws + w.dout, V, rows, w.nz_rows, V, scr, G + sl.f2_b, st)) return rc;
+    hipLaunchKernelGGL((head_out_bwd_kernel<7>), dim3((unsigned)(rows_pad < 2048 ? rows_pad : 2048)), dim3(256), 0, st, ws + w.h2, ws + w.dout,
+                       P + e.f2_w, Hd, rows, rows_pad, ws + w.dh2);
+    LAUNCH_CHECK();
+    if (int rc = launch_colsum(ws + w.dh2, Hd, rows, w.nz_rows, Hd, scr, G + sl.f1_b, st)) return rc;
+    if (int rc = launch_transpose(ws + w.dh2, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
+    if (int rc = launch_transpose(ws + w.h1, rows_pad, Hd, Hd, ws + w.T2, rows_pad, rows_pad, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.T1, ws + w.T2, nullptr, G + sl.f1_w, nullptr, Hd, Hd, (int)rows_pad, (int)rows_pad, Hd, Hd, st)) return rc;   // dW2 = dH2^T H1
+    if (int rc = launch_gemm_t<ACT_MUL_ELUGRAD, 3>(ws + w.dh2, P + tl.f1T, nullptr, ws + w.dh1, ws + w.h1, rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, st)) return rc;
+    if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
+    if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, st)) return rc;
+    if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.T1, ws + w.T2, nullptr, G + sl.f0_w, nullptr, Hd, F, (int)rows_pad, (int)rows_pad, F, F, st)) return rc;     // dW1 = dH1^T concat
+    if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.dh1, P + tl.f0T, nullptr, ws + w.dconcat, nullptr, rows_pad, F, Hd, Hd, F, F, st)) return rc;
+    // ---- 5. encoder backward -----------------------------------------------------------------------------------------
+    {
+        typedef TrbGeom<8, TRAIN_G, 8, 128> Ge;
+        const size_t lds = Ge::lds_floats * sizeof(float);
+        auto kern = cate_enc_bwd_kernel<8, 7, TRAIN_G, 8, 128>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(w.nblk_enc), dim3(256), lds, st, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm,
+                           ws + w.part, gl, ws + w.dtau, B);
+        LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((gl.total + 255) / 256)), dim3(256), 0, st, ws + w.part, w.nblk_enc, gl.total, gl.total,
+                       ws + w.gsum, 1.0f);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(train_unfold_layers_kernel, dim3(32, L), dim3(256), 0, st, ws + w.gsum, gl, S, sl, G, d, dff);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(G + sl.emb_w, ws + w.gsum + gl.emb_w, (size_t)d * V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(G + sl.emb_b, ws + w.gsum + gl.emb_b, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // ---- 6. time-embedding MLP backward --------------------------------------------------------------------------------
+    hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(B), dim3(256), (size_t)d * sizeof(float), st, ws + w.dtau, ws + w.save_pre, d, P + e.t2_w, ws + w.dpre);
+    LAUNCH_CHECK();
+    if (int rc = launch_tn_small<1>(ws + w.dtau, d, ws + w.save_pre, 4 * d, B, w.nz_b, d, 4 * d, scr, G + sl.t2_w, st)) return rc;   // dW2 = dtau^T silu(pre)
+    if (int rc = launch_colsum(ws + w.dtau, d, B, w.nz_b, d, scr, G + sl.t2_b, st)) return rc;
+    if (int rc = launch_tn_small<0>(ws + w.dpre, 4 * d, ws + w.save_e, d, B, w.nz_b, 4 * d, d, scr, G + sl.t1_w, st)) return rc;    // dW1 = dpre^T e
+    if (int rc = launch_colsum(ws + w.dpre, 4 * d, B, w.nz_b, 4 * d, scr, G + sl.t1_b, st)) return rc;
     return 0;
 }
 

@@ -1,0 +1,244 @@
+"""Host mirror of the reference's ``losses.py`` for the score network's DSM training step
+(reference ``losses.py:10-36``, ``:110-168``, ``:171-237``; BASELINE config 3).
+
+``get_sde_loss_fn_nas`` returns a ``loss_fn(model, batch)`` with the reference's signature.  The loss and
+the gradient of every ``CATE`` parameter come from ONE call of ``dnag_cate_dsm_step`` in ``libdnag.so``
+(forward with dropout, loss, hand-derived backward); the returned tensor is attached to the autograd graph
+through a ``torch.autograd.Function`` that only hands those gradients over, so the reference's
+``optimizer.zero_grad(); loss = loss_fn(...); loss.backward(); optimize_fn(...)`` sequence works unchanged.
+PyTorch runs no part of the network.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from . import _lib, sde_lib
+from .cate import CATE, Workspace, positional_table, timestep_frequencies
+
+
+def get_optimizer(config, params):
+    """Reference ``losses.py:10-19``."""
+    if config.optim.optimizer == 'Adam':
+        return optim.Adam(params, lr=config.optim.lr, betas=(config.optim.beta1, 0.999), eps=config.optim.eps,
+                          weight_decay=config.optim.weight_decay)
+    raise NotImplementedError(f'Optimizer {config.optim.optimizer} not supported yet!')
+
+
+def optimization_manager(config):
+    """Reference ``losses.py:22-36``: warm-up, gradient clipping, optimiser step (host side)."""
+
+    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip):
+        if warmup > 0:
+            for g in optimizer.param_groups:
+                g['lr'] = lr * np.minimum(step / warmup, 1.0)
+        if grad_clip >= 0:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
+        optimizer.step()
+
+    return optimize_fn
+
+
+def dropout_mask_layout(dims, batch: int):
+    """Byte offsets of the dropout sites inside the ``keep`` buffer of ``dnag_cate_dsm_step``
+    (``include/dnag.h``): ``{'rows', 'per_layer', 'emb', 'layer0', 'attn', 'sa', 'ffh', 'ffo', 'total'}``."""
+    rows = batch * dims.max_node
+    per_layer = dims.n_head * dims.max_node + 2 * dims.d_model + dims.d_ff
+    return dict(rows=rows, per_layer=per_layer, emb=0, layer0=rows * dims.d_model, attn=0,
+                sa=dims.n_head * dims.max_node, ffh=dims.n_head * dims.max_node + dims.d_model,
+                ffo=dims.n_head * dims.max_node + dims.d_model + dims.d_ff,
+                total=rows * dims.d_model + dims.n_layers * rows * per_layer)
+
+
+def pack_dropout_masks(masks: Dict[str, torch.Tensor], dims, batch: int) -> torch.Tensor:
+    """Keep masks named and shaped like the reference's dropout sites in forward order -- ``emb [B,N,d]``,
+    per layer ``attn{l} [B,H,N,N]``, ``sa{l} [B,N,d]``, ``ffh{l} [B,N,d_ff]``, ``ffo{l} [B,N,d]``
+    (``cate.py:147``, ``transformer.py:19``, ``:80``, ``:54``, ``:108``) -- as the uint8 buffer the kernel reads."""
+    lay = dropout_mask_layout(dims, batch)
+    B, N, d, H, dff = batch, dims.max_node, dims.d_model, dims.n_head, dims.d_ff
+    parts = [masks["emb"].reshape(B * N, d)]
+    for l in range(dims.n_layers):
+        attn = masks[f"attn{l}"].reshape(B, H, N, N).permute(0, 2, 1, 3).reshape(B * N, H * N)   # row = (b, query)
+        parts.append(torch.cat([attn, masks[f"sa{l}"].reshape(B * N, d), masks[f"ffh{l}"].reshape(B * N, dff),
+                                masks[f"ffo{l}"].reshape(B * N, d)], dim=1))
+    flat = torch.cat([p.reshape(-1) for p in parts]).to(torch.uint8).contiguous()
+    assert flat.numel() == lay["total"]
+    return flat
+
+
+class _DsmStep(torch.autograd.Function):
+    """Carries the gradients computed by the HIP step into ``loss.backward()``."""
+
+    @staticmethod
+    def forward(ctx, loss, flat_grads, *params):
+        ctx.shapes = [p.shape for p in params]
+        ctx.save_for_backward(flat_grads)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (flat,) = ctx.saved_tensors
+        outs, o = [], 0
+        for shp in ctx.shapes:
+            n = int(np.prod(shp))
+            outs.append((flat[o:o + n] * grad_out).reshape(shp))
+            o += n
+        return (None, None) + tuple(outs)
+
+
+def dsm_step(model: CATE, sde, x, t, z, mask, *, reduce_mean=True, keep: Optional[torch.Tensor] = None,
+             dropout_p: float = 0.0, need_grads: bool = True):
+    """One call of ``dnag_cate_dsm_step``: returns ``(loss [device scalar], flat_grads or None)`` with
+    ``flat_grads`` in ``state_dict()`` order.  ``t`` [B] and ``z`` [B,N,V] are the random draws of
+    ``losses.py:139`` and ``:141``; ``keep`` the packed dropout masks (None: dropout off)."""
+    lib = _lib.load()
+    if not isinstance(model, CATE):
+        raise NotImplementedError("the HIP training step is built for the CATE score network")
+    dev = _lib.require_device(x, t, z, mask)
+    B, N, V = x.shape
+    dims = model.dims
+    if (N, V) != (dims.max_node, dims.n_vocab):
+        raise ValueError(f"x has shape [*, {N}, {V}], model was built for [*, {dims.max_node}, {dims.n_vocab}]")
+    xf = x.detach().to(torch.float32).contiguous()
+    zf = z.detach().to(torch.float32).contiguous()
+    tf = t.detach().to(torch.float32).contiguous()
+    # sde.marginal_prob on a unit input gives the per-graph mean coefficient and std with the reference's
+    # own torch expressions (sde_lib.py:179-188 / :279-282)
+    mean1, std = sde.marginal_prob(torch.ones(B, 1, 1, device=dev), tf)
+    mean_coef = mean1.reshape(B).to(torch.float32).contiguous()
+    std = std.to(torch.float32).contiguous()
+    if isinstance(sde, sde_lib.VESDE):
+        labels = std                                                      # models/utils.py:109
+    else:
+        labels = (tf * 999).contiguous()                                  # models/utils.py:93
+    m = mask.detach().to(torch.float32).contiguous()
+    if m.dim() == 2:
+        m = m.unsqueeze(0)
+    if m.shape[1:] != (N, N) or m.shape[0] not in (1, B):
+        raise ValueError(f"mask has shape {tuple(m.shape)}, expected [{B}|1, {N}, {N}]")
+    params = [p for p in model.state_dict(keep_vars=True).values()]
+    flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
+    dc = model.dims_c()
+    if flat.numel() != lib.dnag_cate_state_floats(C.byref(dc)):
+        raise RuntimeError("state_dict size does not match the CATE layout")
+    if getattr(model, "_tables_dev", None) is None or model._tables_dev.device != dev:
+        model._tables_dev = torch.cat([positional_table(dims.max_node, dims.d_model, dims.stagewise_pos).reshape(-1),
+                                       timestep_frequencies(dims.d_model)]).contiguous().to(dev)
+    if getattr(model, "_train_ws", None) is None:
+        model._train_ws = Workspace()
+    ws = model._train_ws.get(lib.dnag_train_workspace_bytes(C.byref(dc), B), dev)
+    if keep is not None:
+        if keep.dtype != torch.uint8 or not keep.is_contiguous() or keep.device != dev:
+            raise ValueError("keep must be a contiguous uint8 tensor on the model's device")
+        if keep.numel() != lib.dnag_dropout_mask_bytes(C.byref(dc), B):
+            raise ValueError("keep has the wrong size for this batch (see dropout_mask_layout)")
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    grads = torch.empty_like(flat) if need_grads else None
+    a = _lib.TrainArgsC()
+    a.cate_dims = C.pointer(dc)
+    a.params = _lib.ptr(flat); a.tables = _lib.ptr(model._tables_dev)
+    a.batch = B
+    a.x = _lib.ptr(xf); a.z = _lib.ptr(zf); a.mean_coef = _lib.ptr(mean_coef); a.std = _lib.ptr(std); a.labels = _lib.ptr(labels)
+    a.mask = _lib.ptr(m); a.mask_stride = int(m.shape[0] == B and B > 1)
+    a.score_mode = sde.score_mode
+    a.reduce_mean = int(bool(reduce_mean))
+    a.keep = keep.data_ptr() if keep is not None else None
+    a.dropout_p = float(dropout_p) if keep is not None else 0.0
+    a.loss = _lib.ptr(loss); a.grads = _lib.ptr(grads)
+    a.workspace = ws.data_ptr(); a.workspace_bytes = ws.numel() * 4
+    a.stream = _lib.current_stream(dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.dnag_cate_dsm_step(C.byref(a)), "dnag_cate_dsm_step")
+    return loss.reshape(()), grads
+
+
+def get_sde_loss_fn_nas(sde, train, reduce_mean=True, continuous=True, likelihood_weighting=True, eps=1e-5):
+    """Reference ``losses.py:110-168``.  ``likelihood_weighting=False`` (every shipped config,
+    ``configs/tr_scorenet.py:33``) and ``continuous=True`` only.
+
+    Attributes of the returned function, for tests and reproducible runs:
+      ``loss_fn.draws = (t, z)``          inject the random draws of ``losses.py:139`` / ``:141`` (consumed once);
+      ``loss_fn.dropout_keep = {...}``    inject keep masks (``pack_dropout_masks`` naming; consumed once);
+      ``loss_fn.seed``                    base seed of the on-device Philox dropout masks (incremented per call).
+    """
+    if likelihood_weighting:
+        raise NotImplementedError("likelihood_weighting=True is not built (the shipped configs use False)")
+    if not continuous:
+        raise NotImplementedError("only continuous=True is supported (as in the reference's shipped configs)")
+
+    def loss_fn(model, batch):
+        x, adj, mask = batch                                              # losses.py:137
+        lib = _lib.load()
+        dev = _lib.require_device(x, mask)
+        B = x.shape[0]
+        if loss_fn.draws is not None:
+            t, z = loss_fn.draws
+            loss_fn.draws = None
+        else:
+            t = torch.rand(B, device=dev) * (sde.T - eps) + eps          # :139
+            z = torch.randn_like(x)                                       # :141
+        p = float(getattr(model, "dropout_p", 0.0)) if train else 0.0     # model.train() / .eval(), models/utils.py:63-68
+        keep = None
+        if p > 0.0:
+            if loss_fn.dropout_keep is not None:
+                keep = pack_dropout_masks(loss_fn.dropout_keep, model.dims, B).to(dev)
+                loss_fn.dropout_keep = None
+            else:
+                dc = model.dims_c()
+                keep = torch.empty(lib.dnag_dropout_mask_bytes(C.byref(dc), B), dtype=torch.uint8, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.dnag_dropout_fill(C.byref(dc), B, p, loss_fn.seed, keep.data_ptr(), _lib.current_stream(dev)),
+                               "dnag_dropout_fill")
+                loss_fn.seed += 1
+        need = train and torch.is_grad_enabled()
+        loss, grads = dsm_step(model, sde, x, t.to(dev), z.to(dev), mask, reduce_mean=reduce_mean, keep=keep, dropout_p=p,
+                               need_grads=need)
+        if not need:
+            return loss
+        params = list(model.state_dict(keep_vars=True).values())
+        return _DsmStep.apply(loss, grads, *params)
+
+    loss_fn.draws = None
+    loss_fn.dropout_keep = None
+    loss_fn.seed = 0
+    return loss_fn
+
+
+def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True, likelihood_weighting=False, data='NASBench201'):
+    """Reference ``losses.py:171-237``: one training / evaluation step on ``state = {'model', 'optimizer',
+    'ema', 'step'}``."""
+    if continuous:
+        if data in ['NASBench201', 'ofa']:
+            loss_fn = get_sde_loss_fn_nas(sde, train, reduce_mean=reduce_mean, continuous=True,
+                                          likelihood_weighting=likelihood_weighting)
+        else:
+            raise NotImplementedError(f"Data {data} (search space) is not supported yet.")
+    else:
+        raise NotImplementedError(f"Discrete training for {sde.__class__.__name__} is not implemented.")
+
+    def step_fn(state, batch):
+        model = state['model']
+        if train:
+            optimizer = state['optimizer']
+            optimizer.zero_grad()
+            loss = loss_fn(model, batch)
+            loss.backward()
+            optimize_fn(optimizer, model.parameters(), step=state['step'])
+            state['step'] += 1
+            state['ema'].update(model.parameters())
+        else:
+            with torch.no_grad():
+                ema = state['ema']
+                ema.store(model.parameters())
+                ema.copy_to(model.parameters())
+                loss = loss_fn(model, batch)
+                ema.restore(model.parameters())
+        return loss
+
+    step_fn.loss_fn = loss_fn
+    return step_fn

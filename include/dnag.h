@@ -200,6 +200,52 @@ typedef struct dnag_pc_args {
 
 int dnag_pc_sample(const dnag_pc_args *args);
 
+/* ---- DSM training step (BASELINE config 3) --------------------------------------------------------
+ * Replaces get_sde_loss_fn_nas(...).loss_fn (losses.py:127-166, likelihood_weighting=False) followed by
+ * loss.backward() (losses.py:222-223): the denoising-score-matching loss of one batch and its gradient
+ * wrt every CATE parameter, with the network in training mode (dropout active, models/utils.py:66-68).
+ * The optimiser step, gradient clipping and EMA (losses.py:22-36, models/ema.py) stay with the caller.
+ *
+ * `params` / `grads` are flat fp32 device buffers in state_dict() order (dnag_cate_state_floats); `tables`
+ * is the device copy of the constants dnag_cate_pack takes.  The random draws are inputs: z ~ N(0, 1)
+ * (losses.py:141), and per graph the time draw folded through sde.marginal_prob (losses.py:139, :143) by
+ * the host mirror: mean_coef (VPSDE exp(lmc), VESDE 1), std, and the time condition `labels` (999 t |
+ * sigma(t), models/utils.py:93, :109).  `keep` holds one byte per dropout site element in the layout
+ * below (NULL or dropout_p == 0: no dropout, which is also the eval-mode loss of losses.py:228-233):
+ *     rows = batch * N, row = graph * N + node
+ *     emb [rows][d_model]                                                   (cate.py:147)
+ *     then per layer l:  [rows][n_head * N + d_model + d_ff + d_model] =
+ *       attention probabilities of this query [n_head][N] (transformer.py:19) | self-attention block
+ *       output (:80) | FFN hidden (:54) | FFN output (:108)
+ * dnag_dropout_fill draws it on the device (Philox4x32-10).  grads == NULL: loss only. */
+typedef struct dnag_train_args {
+    const dnag_cate_dims *cate_dims;
+    const float *params;               /* device [dnag_cate_state_floats] */
+    const float *tables;               /* device [dnag_cate_table_floats] */
+    int32_t batch;
+    const float *x;                    /* device [batch][N][V] clean data (datasets_nas.py:11-18 scaling) */
+    const float *z;                    /* device [batch][N][V] */
+    const float *mean_coef;            /* device [batch] */
+    const float *std;                  /* device [batch] */
+    const float *labels;               /* device [batch] */
+    const float *mask;                 /* device [batch][N][N] (mask_stride 1) or [1][N][N] (0) */
+    int32_t mask_stride;
+    int32_t score_mode;                /* DNAG_SCORE_VP or DNAG_SCORE_VE */
+    int32_t reduce_mean;               /* losses.py:151-154 */
+    const uint8_t *keep;               /* device [dnag_dropout_mask_bytes] or NULL */
+    float dropout_p;
+    float *loss;                       /* device [1] */
+    float *grads;                      /* device [dnag_cate_state_floats] or NULL */
+    void *workspace;
+    size_t workspace_bytes;
+    void *stream;
+} dnag_train_args;
+
+size_t dnag_train_workspace_bytes(const dnag_cate_dims *d, int batch);
+size_t dnag_dropout_mask_bytes(const dnag_cate_dims *d, int batch);
+int    dnag_dropout_fill(const dnag_cate_dims *d, int batch, float p, uint64_t seed, uint8_t *keep, void *stream);
+int    dnag_cate_dsm_step(const dnag_train_args *args);
+
 /* ---- exit: threshold (utils.py:244-262) --------------------------------------------------------
  * q[i] = x[i] >= 0.5 ? 1 : 0, n elements, device pointers. */
 int dnag_quantize(const float *x, float *q, size_t n, void *stream);

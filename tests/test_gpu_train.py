@@ -1,0 +1,161 @@
+"""Parity of the HIP DSM training step (dnag_cate_dsm_step through the C ABI, driven by the host mirror of
+the reference's losses.py) with the golden vectors captured from the reference's own loss_fn + backward
+(tests/golden/train_*.npz) and with the CPU oracle on seeded inputs.  Needs an MI355X.
+
+Tolerances: fp32 with a different summation order than autograd on the CPU.  Loss 1e-5 relative; a gradient
+tensor to 5e-5 of its own max (measured ~1e-6 .. 1e-5; the encoder weight gradients sum ~10^2..10^4 rows)."""
+
+import numpy as np
+import pytest
+import torch
+
+from diffusionnag_amd import cate as _cate  # noqa: F401  (registers the model)
+from diffusionnag_amd import losses, mutils, sde_lib, synthetic
+from diffusionnag_amd.specs import CateDims
+from oracle import dnag_oracle as O
+from tests.helpers import golden, score_config
+from tests.test_oracle_golden import train_case
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def make_model(seed=0):
+    m = mutils.create_model(score_config(CateDims(), DEV))
+    m.load_state_dict(synthetic.cate_state_dict(CateDims(), seed=seed, perturb_norms=True))
+    return m
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert np.isfinite(a).all()
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def run_step(model, sde, x, t, z, mask, dropout, train=True, reduce_mean=True):
+    """loss_fn + loss.backward() exactly as the reference's step_fn does (losses.py:221-223)."""
+    fn = losses.get_sde_loss_fn_nas(sde, train=train, reduce_mean=reduce_mean, continuous=True, likelihood_weighting=False)
+    fn.draws = (t.to(DEV), z.to(DEV))
+    if dropout is not None:
+        fn.dropout_keep = {k: v.to(DEV) for k, v in dropout["masks"].items()}
+        model.dropout_p = dropout["p"]
+    else:
+        model.dropout_p = 0.0
+    model.train(train)
+    model.zero_grad()
+    loss = fn(model, (x.to(DEV), mask.to(DEV), mask.to(DEV)))
+    if train:
+        loss.backward()
+    torch.cuda.synchronize()
+    return loss
+
+
+@pytest.mark.parametrize("name", ["train_nb201_vp_nodrop", "train_nb201_vp_drop", "train_nb201_ve_drop"])
+def test_dsm_step_against_reference_golden(name):
+    g = golden(name)
+    x, t, z, dropout = train_case(g)
+    model = make_model(0)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000) if str(g["sde_kind"]) == "vp" else sde_lib.VESDE(0.1, 5.0, 1000)
+    maskB = torch.from_numpy(g["mask"]).unsqueeze(0).repeat(x.shape[0], 1, 1)
+    loss = run_step(model, sde, x, t, z, maskB, dropout)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    params = dict(model.named_parameters())
+    names = list(model.state_dict().keys())
+    norms = np.array([float(params[k].grad.double().norm()) for k in names])
+    assert np.abs(norms - g["grad_norms"]).max() <= 1e-4 * np.abs(g["grad_norms"]).max()
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-7)
+    for key in g:
+        if key.startswith("grad:"):
+            k = key[5:]
+            got = params[k[:-4]].grad[:8] if k.endswith("[:8]") else params[k].grad
+            e = rel_err(got.cpu().numpy(), g[key])
+            assert e <= 5e-5, f"{key}: {e:.3e}"
+
+
+@pytest.mark.parametrize("sde_kind,B,reduce_mean", [("vp", 19, True), ("ve", 9, False)])
+def test_dsm_step_against_oracle_ragged_batch(sde_kind, B, reduce_mean):
+    """A batch that does not fill the last workgroup, per-graph masks (raw adjacency and its closure mixed),
+    dropout active: every gradient tensor against the oracle's autograd."""
+    rs = np.random.RandomState(7)
+    ops = rs.randint(0, 7, size=(B, 8))
+    x = np.full((B, 8, 7), -1.0, np.float32)
+    x[np.arange(B)[:, None], np.arange(8)[None, :], ops] = 1.0
+    x = torch.from_numpy(x)
+    t = torch.from_numpy(rs.uniform(1e-5, 1, size=B).astype(np.float32))
+    z = torch.from_numpy(rs.standard_normal((B, 8, 7)).astype(np.float32))
+    adj = O.nb201_adj()
+    clo = O.aug_mask(adj.unsqueeze(0))[0]
+    mask = torch.stack([adj if i % 2 == 0 else clo for i in range(B)])
+    p = 0.1
+    dropout = {"p": p, "masks": {k: torch.from_numpy((rs.uniform(0, 1, size=shape) >= p).astype(np.float32))
+                                 for k, shape in O.dropout_sites(B, 8).items()}}
+    sd = synthetic.cate_state_dict(CateDims(), seed=3, perturb_norms=True)
+    osde = O.VPSDE(0.1, 20.0, 1000) if sde_kind == "vp" else O.VESDE(0.1, 5.0, 1000)
+    want_loss, want = O.dsm_loss_and_grads(sd, osde, x, t, z, mask, dropout=dropout, reduce_mean=reduce_mean)
+    model = make_model(3)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000) if sde_kind == "vp" else sde_lib.VESDE(0.1, 5.0, 1000)
+    loss = run_step(model, sde, x, t, z, mask, dropout, reduce_mean=reduce_mean)
+    assert abs(float(loss) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
+    worst = ("", 0.0)
+    for k, prm in model.named_parameters():
+        e = rel_err(prm.grad.cpu().numpy(), want[k].numpy())
+        if e > worst[1]:
+            worst = (k, e)
+        assert e <= 5e-5, f"{k}: {e:.3e}"
+    print("worst gradient tensor:", worst)
+
+
+def test_eval_loss_and_no_grad():
+    """train=False (losses.py:228-233): dropout off, no gradients; equals the oracle's eval-mode loss."""
+    g = golden("train_nb201_vp_nodrop")
+    x, t, z, _ = train_case(g)
+    model = make_model(0)
+    maskB = torch.from_numpy(g["mask"]).unsqueeze(0).repeat(x.shape[0], 1, 1)
+    with torch.no_grad():
+        loss = run_step(model, sde_lib.VPSDE(0.1, 20.0, 1000), x, t, z, maskB, None, train=False)
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert all(p.grad is None for p in model.parameters())
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 3 size (B = 1024).  Size-independent properties: (i) a batch made of two copies of a
+    half batch has the half batch's loss and gradients (both are batch means); (ii) the on-device Philox dropout
+    masks keep ~ 1 - p of the sites and give finite gradients."""
+    B = 1024
+    rs = np.random.RandomState(11)
+    ops = rs.randint(0, 7, size=(B // 2, 8))
+    x = np.full((B // 2, 8, 7), -1.0, np.float32)
+    x[np.arange(B // 2)[:, None], np.arange(8)[None, :], ops] = 1.0
+    x = torch.from_numpy(x)
+    t = torch.from_numpy(rs.uniform(1e-5, 1, size=B // 2).astype(np.float32))
+    z = torch.from_numpy(rs.standard_normal((B // 2, 8, 7)).astype(np.float32))
+    mask = O.nb201_adj().unsqueeze(0).repeat(B // 2, 1, 1)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    model = make_model(0)
+    l1 = run_step(model, sde, x, t, z, mask, None)
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    l2 = run_step(model, sde, torch.cat([x, x]), torch.cat([t, t]), torch.cat([z, z]), torch.cat([mask, mask]), None)
+    assert abs(float(l1) - float(l2)) <= 2e-6 * abs(float(l1))
+    for k, p in model.named_parameters():
+        e = rel_err(p.grad.cpu().numpy(), g1[k].cpu().numpy())
+        assert e <= 2e-5, f"{k}: {e:.3e}"
+    # Philox dropout
+    import ctypes as C
+    from diffusionnag_amd import _lib
+    lib = _lib.load()
+    dc = model.dims_c()
+    n = lib.dnag_dropout_mask_bytes(C.byref(dc), B)
+    keep = torch.empty(n, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.dnag_dropout_fill(C.byref(dc), B, 0.1, 5, keep.data_ptr(), _lib.current_stream(torch.device(DEV))), "fill")
+    rate = float(keep.float().mean())
+    assert abs(rate - 0.9) < 2e-3, rate
+    fn = losses.get_sde_loss_fn_nas(sde, train=True, reduce_mean=True, continuous=True, likelihood_weighting=False)
+    model.dropout_p = 0.1
+    model.train()
+    model.zero_grad()
+    xx, mm = torch.cat([x, x]).to(DEV), torch.cat([mask, mask]).to(DEV)
+    loss = fn(model, (xx, mm, mm))
+    loss.backward()
+    assert np.isfinite(float(loss))
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())

@@ -329,3 +329,88 @@ def test_gather_world_size_2_gloo(tmp_path):
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+# ----------------------------------------------------------------------------------------------------
+# DSM training step: host logic (the kernels are covered by tests/test_gpu_train.py)
+# ----------------------------------------------------------------------------------------------------
+def test_train_args_struct_matches_header():
+    header = open(os.path.join(REPO, "include", "dnag.h")).read()
+    body = header[header.index("typedef struct dnag_train_args {"):header.index("} dnag_train_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    body = body[body.index("{") + 1:]
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            for part in decl.split(","):
+                names.append(re.sub(r"[\*\s]", " ", part).split()[-1])
+    assert names == [f[0] for f in _lib.TrainArgsC._fields_]
+
+
+def test_dropout_mask_packing_layout():
+    from diffusionnag_amd import losses
+    lib = _lib.load()
+    dims = CateDims()
+    B = 3
+    d = _lib.CateDimsC(8, 7, 64, 8, 128, 12, 0)
+    lay = losses.dropout_mask_layout(dims, B)
+    assert lay["total"] == lib.dnag_dropout_mask_bytes(C.byref(d), B)
+    # every site element gets a distinct tag -> find it where include/dnag.h says it lives
+    sites = O.dropout_sites(B, 8)
+    rs = np.random.RandomState(0)
+    masks = {k: torch.from_numpy(rs.randint(0, 2, size=s).astype(np.float32)) for k, s in sites.items()}
+    flat = losses.pack_dropout_masks(masks, dims, B).numpy()
+    rows, pl = lay["rows"], lay["per_layer"]
+    b, n, l = 2, 5, 7
+    row = b * 8 + n
+    assert (flat[row * 64:(row + 1) * 64] == masks["emb"][b, n].numpy()).all()
+    base = lay["layer0"] + l * rows * pl + row * pl
+    for h in range(8):
+        assert (flat[base + h * 8: base + h * 8 + 8] == masks[f"attn{l}"][b, h, n].numpy()).all()
+    assert (flat[base + lay["sa"]: base + lay["sa"] + 64] == masks[f"sa{l}"][b, n].numpy()).all()
+    assert (flat[base + lay["ffh"]: base + lay["ffh"] + 128] == masks[f"ffh{l}"][b, n].numpy()).all()
+    assert (flat[base + lay["ffo"]: base + lay["ffo"] + 64] == masks[f"ffo{l}"][b, n].numpy()).all()
+
+
+def test_training_step_has_no_cpu_fallback_and_rejects_bad_arguments():
+    from diffusionnag_amd import losses
+    lib = _lib.load()
+    assert lib.dnag_cate_dsm_step(C.byref(_lib.TrainArgsC())) == -1          # NULL dims rejected before any launch
+    ofa = _lib.CateDimsC(20, 9, 64, 8, 128, 12, 1)
+    a = _lib.TrainArgsC()
+    a.cate_dims = C.pointer(ofa)
+    assert lib.dnag_cate_dsm_step(C.byref(a)) == -1 and b"NAS-Bench-201" in lib.dnag_last_error()
+    d = _lib.CateDimsC(8, 7, 64, 8, 128, 12, 0)
+    assert lib.dnag_train_workspace_bytes(C.byref(d), 1024) > 1024 * 8 * (768 + 4 * 1536) * 4
+    with pytest.raises(NotImplementedError):
+        losses.get_sde_loss_fn_nas(sde_lib.VPSDE(), train=True, likelihood_weighting=True)
+    model = mutils.create_model(score_config(CateDims(), "cpu"))
+    fn = losses.get_sde_loss_fn_nas(sde_lib.VPSDE(), train=True, reduce_mean=True, continuous=True, likelihood_weighting=False)
+    x = torch.zeros(2, 8, 7)
+    m = torch.zeros(2, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fn(model, (x, m, m))
+
+
+def test_ema_mirror_matches_reference_formula():
+    from diffusionnag_amd.ema import ExponentialMovingAverage
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    ema = ExponentialMovingAverage(ps, decay=0.9999)
+    shadow = [p.detach().clone() for p in ps]
+    for step in range(1, 4):
+        with torch.no_grad():
+            for p in ps:
+                p.add_(torch.randn_like(p))
+        ema.update(ps)
+        decay = min(0.9999, (1 + step) / (10 + step))                 # models/ema.py:37
+        shadow = [s - (1.0 - decay) * (s - p.detach()) for s, p in zip(shadow, ps)]
+    for s, e in zip(shadow, ema.shadow_params):
+        assert torch.equal(s, e)
+    ema.store(ps)
+    ema.copy_to(ps)
+    assert all(torch.equal(p.data, s) for p, s in zip(ps, ema.shadow_params))
+    ema.restore(ps)
+    assert not torch.equal(ps[0].data, ema.shadow_params[0])
+    assert set(ema.state_dict()) == {"decay", "num_updates", "shadow_params"}
