@@ -30,6 +30,7 @@ EXPORTS = (
     "dnag_predcate_workspace_bytes", "dnag_workspace_bytes", "dnag_workspace_bytes_predcate",
     "dnag_cate_forward", "dnag_pred_forward_grad", "dnag_predcate_forward_grad", "dnag_pc_sample",
     "dnag_quantize", "dnag_timing_begin", "dnag_timing_read", "dnag_timing_end",
+    "dnag_nb201_seen_reset", "dnag_nb201_validity",
     "dnag_train_workspace_bytes", "dnag_dropout_mask_bytes", "dnag_dropout_fill", "dnag_cate_dsm_step",
 )
 
@@ -134,6 +135,10 @@ def load() -> C.CDLL:
     lib.dnag_timing_read.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dnag_timing_end.restype = i32
     lib.dnag_timing_end.argtypes = []
+    lib.dnag_nb201_seen_reset.restype = i32
+    lib.dnag_nb201_seen_reset.argtypes = [vp, vp]
+    lib.dnag_nb201_validity.restype = i32
+    lib.dnag_nb201_validity.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp]
     lib.dnag_train_workspace_bytes.restype = sz
     lib.dnag_train_workspace_bytes.argtypes = [C.POINTER(CateDimsC), i32]
     lib.dnag_dropout_mask_bytes.restype = sz

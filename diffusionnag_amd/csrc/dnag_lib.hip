@@ -16,6 +16,7 @@
 #include "dnag_predictor.hip.h"
 #include "dnag_predcate.hip.h"
 #include "dnag_train.hip.h"
+#include "dnag_arch.hip.h"
 
 // ---------------------------------------------------------------------------------------------
 // errors
@@ -1044,6 +1045,29 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = launch_colsum(ws + w.dtau, d, B, w.nz_b, d, scr, G + sl.t2_b, st)) return rc;
     if (int rc = launch_tn_small<0>(ws + w.dpre, 4 * d, ws + w.save_e, d, B, w.nz_b, 4 * d, d, scr, G + sl.t1_w, st)) return rc;    // dW1 = dpre^T e
     if (int rc = launch_colsum(ws + w.dpre, 4 * d, B, w.nz_b, 4 * d, scr, G + sl.t1_b, st)) return rc;
+    return 0;
+}
+
+extern "C" int dnag_nb201_seen_reset(int32_t *first_seen, void *stream) {
+    if (!first_seen) return fail(DNAG_E_ARG, "NULL pointer");
+    hipLaunchKernelGGL(fill_i32_kernel, dim3(16), dim3(1024), 0, (hipStream_t)stream, first_seen, (size_t)NB201_NCODES, (int32_t)NB201_UNSEEN);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dnag_nb201_validity(const float *x, int batch, int32_t *status, int32_t *code, int32_t *first_seen, int32_t index_base,
+                                   int32_t *counts, void *stream) {
+    if (!x || !status || !code) return fail(DNAG_E_ARG, "NULL pointer");
+    if (batch < 0 || index_base < 0 || (int64_t)index_base + batch >= (int64_t)NB201_UNSEEN) return fail(DNAG_E_ARG, "batch=%d index_base=%d", batch, index_base);
+    hipStream_t st = (hipStream_t)stream;
+    if (batch > 0) {
+        hipLaunchKernelGGL(nb201_validity_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, x, batch, status, code, first_seen, index_base);
+        LAUNCH_CHECK();
+    }
+    if (counts) {
+        hipLaunchKernelGGL(nb201_count_kernel, dim3(1), dim3(1024), 0, st, status, batch, first_seen, counts);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
 

@@ -246,6 +246,23 @@ size_t dnag_dropout_mask_bytes(const dnag_cate_dims *d, int batch);
 int    dnag_dropout_fill(const dnag_cate_dims *d, int batch, float p, uint64_t seed, uint8_t *keep, void *stream);
 int    dnag_cate_dsm_step(const dnag_train_args *args);
 
+/* ---- exit of a sampling round, NAS-Bench-201 ---------------------------------
+ * Replaces quantize (utils.py:244-262) + is_valid_NAS201_x (analysis/arch_functions.py:284-329) + the argmax
+ * decode (:209-216) that BasicArchMetricsMeta.compute_validity (:95-118) runs per sample on the host, and the
+ * `set(all_samples)` bookkeeping of generate_archs_meta (main_exp/diffusion/run_lib.py:141-152).
+ *   x [batch][8][7]  sampler output ((x_mean + 1) / 2 scale); thresholded at 0.5 here
+ *   status [batch]   -1 valid | 1 MULTIPLE_NODE_TYPES | 2 No_START_END | 3 INTERM_START_END (:308-313)
+ *   code [batch]     sum_i (argmax(row i+1) - 2) 5^i, i = 0..5 (six cell edges, operation types 2..6), -1 if invalid
+ *   first_seen [DNAG_NB201_NCODES] (may be NULL) persistent across rounds: the smallest index_base + graph index
+ *                    that produced each code; dnag_nb201_seen_reset sets every entry to DNAG_NB201_UNSEEN
+ *   counts [2] (may be NULL): valid graphs of this call, distinct codes seen so far.
+ * All pointers are device pointers; nothing synchronises. */
+#define DNAG_NB201_NCODES 15625
+#define DNAG_NB201_UNSEEN 0x7fffffff
+int dnag_nb201_seen_reset(int32_t *first_seen, void *stream);
+int dnag_nb201_validity(const float *x, int batch, int32_t *status, int32_t *code, int32_t *first_seen,
+                        int32_t index_base, int32_t *counts, void *stream);
+
 /* ---- exit: threshold (utils.py:244-262) --------------------------------------------------------
  * q[i] = x[i] >= 0.5 ? 1 : 0, n elements, device pointers. */
 int dnag_quantize(const float *x, float *q, size_t n, void *stream);

@@ -22,6 +22,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -497,3 +498,49 @@ def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3,
                 rec.update(score_p=s2, cgrad_p=cg2, total_p=grad2, x_mean=x_mean.clone(), x_pred=x.clone())
                 record.append(rec)
     return inverse_scaler(x_mean)
+
+
+# ----------------------------------------------------------------------------------------------
+# Exit of a sampling round: validity rules and architecture strings of NAS-Bench-201
+# (analysis/arch_functions.py:209-256, :284-329; BasicArchMetricsMeta.compute_validity :95-118)
+# ----------------------------------------------------------------------------------------------
+NB201_OPS = ['input', 'output', 'none', 'skip_connect', 'nor_conv_1x1', 'nor_conv_3x3', 'avg_pool_3x3']   # :88
+
+
+def is_valid_nas201_x(x, START_TYPE: int = 0, END_TYPE: int = 1):
+    """arch_functions.py:316-329 on a quantised [8, 7] array: (is_valid, error code) with the codes of
+    :308-313 (1 MULTIPLE_NODE_TYPES, 2 No_START_END, 3 INTERM_START_END, -1 NO_ERROR)."""
+    x = np.asarray(x)
+    for row in x:                                                               # :284-288
+        if int(np.sum(row)) != 1:
+            return False, 1
+    if x[0][START_TYPE] != 1 or x[-1][END_TYPE] != 1:                           # :291-296
+        return False, 2
+    for row in x[1:-1]:                                                         # :299-305
+        if row[START_TYPE] == 1 or row[END_TYPE] == 1:
+            return False, 3
+    return True, -1
+
+
+def nb201_arch_code(x) -> int:
+    """The six edge operations of a VALID cell as one integer: sum_i (argmax(x[i+1]) - 2) 5^i; the argmax
+    decode is arch_functions.py:209-216 (edge order (1,0), (2,0), (2,1), (3,0), (3,1), (3,2))."""
+    x = np.asarray(x)
+    return int(sum((int(np.argmax(x[i + 1])) - 2) * 5 ** i for i in range(6)))
+
+
+def nb201_code_to_string(code: int, ops=NB201_OPS) -> str:
+    """arch_functions.py:252-255 from the integer code."""
+    t = [ops[(code // 5 ** i) % 5 + 2] for i in range(6)]
+    return '|{}~0|+|{}~0|{}~1|+|{}~0|{}~1|{}~2|'.format(*t)
+
+
+def compute_validity(generated, ops=NB201_OPS):
+    """BasicArchMetricsMeta.compute_validity (:95-118) on a list of quantised [8, 7] arrays:
+    (error codes, strings or None per sample)."""
+    errs, strs = [], []
+    for x in generated:
+        ok, err = is_valid_nas201_x(x, ops.index('input'), ops.index('output'))
+        errs.append(err)
+        strs.append(nb201_code_to_string(nb201_arch_code(x), ops) if ok else None)
+    return errs, strs

@@ -265,3 +265,18 @@ def test_dsm_loss_and_parameter_gradients(golden, name):
             k = key[5:]
             got = grads[k[:-4]][:8] if k.endswith("[:8]") else grads[k]
             close(got, g[key], 0, 2e-5 * np.abs(g[key]).max() + 1e-9)
+
+
+# ----------------------------------------------------------------------------------------------------
+# Exit of a sampling round: validity rules and strings (tests/golden/make_golden_validity.py)
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["validity_nb201_a", "validity_nb201_b"])
+def test_validity_rules_and_strings(golden, name):
+    g = golden(name)
+    q = [(xi >= 0.5).astype(np.float32) for xi in g["x"]]             # utils.py:254-255
+    errs, strs = O.compute_validity(q)
+    assert errs == list(g["error_types"])
+    assert [s if s is not None else "" for s in strs] == list(g["all_arch_str"])
+    valid = [s for s in strs if s is not None]
+    assert len(valid) / len(strs) == float(g["validity"])
+    assert len(set(valid)) == int(g["n_unique"])
