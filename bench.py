@@ -97,6 +97,57 @@ def cpu_baseline(seconds=12.0):
                       f"x1000 steps per trajectory"}
 
 
+def bench_train(a):
+    """BASELINE configs[2]: NAS-Bench-201 score-network DSM training step (loss + gradient of every parameter,
+    dropout 0.1 with on-device Philox masks) at batch 1024 on one GPU.  A step = dnag_cate_dsm_step on resident
+    inputs (the optimiser is the caller's, losses.py:22-36).  Algorithmic FLOPs: 3 x 63.36 MFLOP per graph
+    (forward + data gradient + weight gradient)."""
+    import ctypes as C
+    from diffusionnag_amd import losses
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    B = 1024 if a.batch_per_gpu == 4096 else a.batch_per_gpu
+    steps = max(a.steps, 20)
+    dims = CateDims()
+    model = mutils.create_model(score_config(dev, dims))
+    model.load_state_dict(synthetic.cate_state_dict(dims, seed=0))
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    g = torch.Generator().manual_seed(0)
+    ops = torch.randint(0, 7, (B, 8), generator=g)
+    x = (torch.nn.functional.one_hot(ops, 7).float() * 2 - 1).to(dev)
+    t = (torch.rand(B, generator=g) * (1 - 1e-5) + 1e-5).to(dev)
+    z = torch.randn(B, 8, 7, generator=g).to(dev)
+    mask = utils.nb201_adj().unsqueeze(0).repeat(B, 1, 1).to(dev)
+    lib = _lib.load()
+    dc = model.dims_c()
+    keep = torch.empty(lib.dnag_dropout_mask_bytes(C.byref(dc), B), dtype=torch.uint8, device=dev)
+
+    def step(i):
+        _lib.check(lib.dnag_dropout_fill(C.byref(dc), B, 0.1, i, keep.data_ptr(), _lib.current_stream(dev)), "dnag_dropout_fill")
+        return losses.dsm_step(model, sde, x, t, z, mask, reduce_mean=True, keep=keep, dropout_p=0.1)
+
+    for i in range(max(a.warmup, 3)):
+        loss, grads = step(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss, grads = step(100 + i)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    flop = 3 * 63.36e6 * B
+    line = {"metric": "DSM training steps/sec (forward + backward), NB201", "value": steps / dt, "unit": "steps/s", "n_gpus": 1,
+            "steps": steps, "warmup": max(a.warmup, 3), "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]: NAS-Bench-201 score-network DSM training step (forward+backward), batch {B}, "
+                                   "VPSDE beta 0.1-20, dropout 0.1 (Philox masks on device), raw adjacency mask, random-init weights",
+                       "batch_per_gpu": B, "includes": "state_dict flatten + on-device weight packing + forward + loss + backward; "
+                                                      "optimizer step excluded (host side, as in the reference)"},
+            "graphs_per_s": B * steps / dt, "whole_step_tflops": flop * steps / dt / 1e12,
+            "whole_step_frac_of_f32_mfma_peak": flop * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "loss": float(loss), "grads_finite": bool(torch.isfinite(grads).all())}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -105,10 +156,13 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--sde-steps", type=int, default=1000, help="PC steps per trajectory (1000 = the full reverse SDE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["nb201", "ofa"], default="nb201",
+    ap.add_argument("--workload", choices=["nb201", "ofa", "train"], default="nb201",
                     help="nb201 = BASELINE configs[1] (the headline metric); ofa = configs[3] (20x9 graphs, MetaPredictorCATE), "
-                         "a side measurement that never replaces the headline line")
+                         "a side measurement that never replaces the headline line; train = configs[2] (DSM training step, "
+                         "forward + backward, batch 1024), also a side measurement")
     a = ap.parse_args()
+    if a.workload == "train":
+        return bench_train(a)
 
     rank, world, local = D.init_from_env()
     if world != a.gpus:

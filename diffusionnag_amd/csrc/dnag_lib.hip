@@ -1057,7 +1057,7 @@ extern "C" int dnag_nb201_seen_reset(int32_t *first_seen, void *stream) {
 
 extern "C" int dnag_nb201_validity(const float *x, int batch, int32_t *status, int32_t *code, int32_t *first_seen, int32_t index_base,
                                    int32_t *counts, void *stream) {
-    if (!x || !status || !code) return fail(DNAG_E_ARG, "NULL pointer");
+    if (batch > 0 && (!x || !status || !code)) return fail(DNAG_E_ARG, "NULL pointer");
     if (batch < 0 || index_base < 0 || (int64_t)index_base + batch >= (int64_t)NB201_UNSEEN) return fail(DNAG_E_ARG, "batch=%d index_base=%d", batch, index_base);
     hipStream_t st = (hipStream_t)stream;
     if (batch > 0) {

@@ -1,0 +1,27 @@
+#!/bin/bash
+# One GPU-box visit: new tests, whole GPU suite, bench lines, rocprof summary.  Each step has its own time
+# limit; a step that ends by signal / abort / timeout stops the script (an ordinary test failure does not).
+mkdir -p gpurun_out
+run() {   # run <seconds> <log> <cmd...>
+    local secs=$1 log=$2; shift 2
+    timeout -k 10 "$secs" "$@" > "gpurun_out/$log" 2>&1
+    local rc=$?
+    echo "[$log] rc=$rc"
+    if [ $rc -ne 0 ] && [ $rc -ne 1 ]; then echo "stopping: $log ended with $rc"; tail -5 "gpurun_out/$log"; exit $rc; fi
+    return 0
+}
+for step in "$@"; do
+case $step in
+  new)    run 300 new_tests.log python -u -m pytest tests/test_gpu_train.py tests/test_gpu_validity.py -q -s --timeout 120 --timeout-method thread; tail -25 gpurun_out/new_tests.log ;;
+  suite)  run 600 gpu_tests.log python -u -m pytest tests -m gpu -q --timeout 120 --timeout-method thread; tail -5 gpurun_out/gpu_tests.log ;;
+  bench)  run 300 bench_default.log python bench.py; tail -1 gpurun_out/bench_default.log ;;
+  train)  run 200 bench_train.log python bench.py --workload train; tail -1 gpurun_out/bench_train.log ;;
+  ofa)    run 300 bench_ofa.log python bench.py --workload ofa --no-cpu-baseline; tail -1 gpurun_out/bench_ofa.log ;;
+  prof)   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
+          run 300 prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
+          tail -1 gpurun_out/prof.log ;;
+  proftrain) run 200 prof_train.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python3 bench.py --workload train --steps 20
+          tail -1 gpurun_out/prof_train.log ;;
+  smoke)  run 200 smoke.log python __graft_entry__.py smoke; tail -2 gpurun_out/smoke.log ;;
+esac
+done

@@ -26,11 +26,15 @@ def make_model(seed=0):
     return m
 
 
+ATOL = 2e-7   # gradients that are zero analytically (the key bias: softmax is shift invariant) are fp32 noise
+
+
 def rel_err(a, b):
+    """max|a - b| relative to max|b|, after forgiving ATOL of absolute noise."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     assert np.isfinite(a).all()
-    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+    return max(np.abs(a - b).max() - ATOL, 0.0) / (np.abs(b).max() + 1e-30)
 
 
 def run_step(model, sde, x, t, z, mask, dropout, train=True, reduce_mean=True):
@@ -59,7 +63,7 @@ def test_dsm_step_against_reference_golden(name):
     sde = sde_lib.VPSDE(0.1, 20.0, 1000) if str(g["sde_kind"]) == "vp" else sde_lib.VESDE(0.1, 5.0, 1000)
     maskB = torch.from_numpy(g["mask"]).unsqueeze(0).repeat(x.shape[0], 1, 1)
     loss = run_step(model, sde, x, t, z, maskB, dropout)
-    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     params = dict(model.named_parameters())
     names = list(model.state_dict().keys())
     norms = np.array([float(params[k].grad.double().norm()) for k in names])
@@ -85,7 +89,7 @@ def test_dsm_step_against_oracle_ragged_batch(sde_kind, B, reduce_mean):
     t = torch.from_numpy(rs.uniform(1e-5, 1, size=B).astype(np.float32))
     z = torch.from_numpy(rs.standard_normal((B, 8, 7)).astype(np.float32))
     adj = O.nb201_adj()
-    clo = O.aug_mask(adj.unsqueeze(0))[0]
+    clo = torch.as_tensor(O.floyed(adj.clone()), dtype=torch.float32)
     mask = torch.stack([adj if i % 2 == 0 else clo for i in range(B)])
     p = 0.1
     dropout = {"p": p, "masks": {k: torch.from_numpy((rs.uniform(0, 1, size=shape) >= p).astype(np.float32))
@@ -96,7 +100,7 @@ def test_dsm_step_against_oracle_ragged_batch(sde_kind, B, reduce_mean):
     model = make_model(3)
     sde = sde_lib.VPSDE(0.1, 20.0, 1000) if sde_kind == "vp" else sde_lib.VESDE(0.1, 5.0, 1000)
     loss = run_step(model, sde, x, t, z, mask, dropout, reduce_mean=reduce_mean)
-    assert abs(float(loss) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
+    assert abs(float(loss.detach()) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
     worst = ("", 0.0)
     for k, prm in model.named_parameters():
         e = rel_err(prm.grad.cpu().numpy(), want[k].numpy())
@@ -114,7 +118,7 @@ def test_eval_loss_and_no_grad():
     maskB = torch.from_numpy(g["mask"]).unsqueeze(0).repeat(x.shape[0], 1, 1)
     with torch.no_grad():
         loss = run_step(model, sde_lib.VPSDE(0.1, 20.0, 1000), x, t, z, maskB, None, train=False)
-    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
     assert all(p.grad is None for p in model.parameters())
 
 
@@ -136,7 +140,7 @@ def test_full_size_batch_properties():
     l1 = run_step(model, sde, x, t, z, mask, None)
     g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
     l2 = run_step(model, sde, torch.cat([x, x]), torch.cat([t, t]), torch.cat([z, z]), torch.cat([mask, mask]), None)
-    assert abs(float(l1) - float(l2)) <= 2e-6 * abs(float(l1))
+    assert abs(float(l1.detach()) - float(l2.detach())) <= 2e-6 * abs(float(l1.detach()))
     for k, p in model.named_parameters():
         e = rel_err(p.grad.cpu().numpy(), g1[k].cpu().numpy())
         assert e <= 2e-5, f"{k}: {e:.3e}"
