@@ -27,6 +27,8 @@ enum { ACT_NONE = 0, ACT_ELU = 1, ACT_TANH = 2, ACT_MUL_ELUGRAD = 3 };
 // <= Nout columns are stored).  bias may be null.
 // ACT_MUL_ELUGRAD multiplies by elu'(z) given aux = elu(z): 1 for aux > 0, else aux + 1 (backward
 // pass of an ELU layer).  TAG only separates instantiations in profiles.
+// Split-K: with gridDim.y = S > 1, slice y reduces K range [y K/S, (y+1) K/S) and stores its partial product
+// at C + y * M * ldc (callers pass ACT_NONE without bias and sum the S slices in a fixed order afterwards).
 template <int ACT, int TAG>
 __global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                                const float *__restrict__ bias, float *__restrict__ C,
@@ -47,8 +49,11 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const floa
     const int tm = wg / nbn, tn = wg - tm * nbn;
 
     const int lrow = tid / GEMM_TPR, lk = (tid % GEMM_TPR) * 4;
-    const float *Ag = A + (size_t)(tm * GEMM_BM + lrow) * lda + lk;
-    const float *Wg = W + (size_t)(tn * GEMM_BN + lrow) * K + lk;
+    const int KT = K / GEMM_BK / (int)gridDim.y;          // k tiles of this slice
+    const int kbase = (int)blockIdx.y * KT * GEMM_BK;
+    const float *Ag = A + (size_t)(tm * GEMM_BM + lrow) * lda + lk + kbase;
+    const float *Wg = W + (size_t)(tn * GEMM_BN + lrow) * K + lk + kbase;
+    C += (size_t)blockIdx.y * (size_t)M * ldc;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -63,7 +68,6 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_bias_act_kernel(const floa
     // loads of tile kt+2 are issued right after, so neither the global latency nor the ds_write burst
     // sits between the last MFMA of a tile and the barrier.
     v4f ra[GEMM_NP], rb[GEMM_NP];
-    const int KT = K / GEMM_BK;
     auto gload = [&](int kt) {
 #pragma unroll
         for (int p = 0; p < GEMM_NP; ++p) {

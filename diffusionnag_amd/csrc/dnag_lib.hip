@@ -437,11 +437,12 @@ static int env_int(const char *name) { const char *v = getenv(name); return v ? 
 // C = act(A W^T + bias); `timed` marks the launches bench.py's roofline is computed on (final.linears.1)
 template <int ACT, int TAG>
 static int launch_gemm_t(const float *A, const float *W, const float *bias, float *C, const float *aux, size_t M, int Nout, int K,
-                         int lda, int ldc, int nvalid, hipStream_t st) {
-    if (M % GEMM_BM || Nout % GEMM_BN || K % GEMM_BK || lda % 4 || nvalid > Nout || nvalid > ldc)
-        return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d (lda %d ldc %d nvalid %d) not tile aligned", M, Nout, K, lda, ldc, nvalid);
+                         int lda, int ldc, int nvalid, hipStream_t st, int splitk = 1) {
+    if (M % GEMM_BM || Nout % GEMM_BN || K % (GEMM_BK * splitk) || lda % 4 || nvalid > Nout || nvalid > ldc)
+        return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d (lda %d ldc %d nvalid %d split %d) not tile aligned", M, Nout, K, lda, ldc, nvalid, splitk);
+    if (splitk > 1 && (ACT != ACT_NONE || bias)) return fail(DNAG_E_ARG, "split-K gemm takes no bias / activation");
     const int grid = (int)(M / GEMM_BM) * (Nout / GEMM_BN);
-    hipLaunchKernelGGL((gemm_bias_act_kernel<ACT, TAG>), dim3(grid), dim3(256), 0, st, A, W, bias, C, aux, (int)M, Nout, K, lda, ldc, nvalid);
+    hipLaunchKernelGGL((gemm_bias_act_kernel<ACT, TAG>), dim3(grid, splitk), dim3(256), 0, st, A, W, bias, C, aux, (int)M, Nout, K, lda, ldc, nvalid);
     LAUNCH_CHECK();
     return 0;
 }
@@ -815,7 +816,7 @@ struct TrainWs {
     size_t rows, rows_pad;
     int nblk_enc, nz_rows, nz_b;
     size_t packed, temb, save_e, save_pre, dpre, dtau, xt, concat, h1, h2, out, dout, dh2, dh1, dconcat, T1, T2;
-    size_t sv_h, sv_h1, sv_qkv, sv_f, part, gsum, scratch, lossp, total;
+    size_t sv_h, sv_h1, sv_qkv, sv_f, part, gsum, scratch, splitk, lossp, total;
 };
 #define TRAIN_G 8
 #define TRAIN_LOSS_BLOCKS 128
@@ -857,6 +858,7 @@ static TrainWs train_ws(const dnag_cate_dims &c, int batch) {
     w.gsum = take(gl.total);
     const size_t big = (V * Hd > 4 * d * d ? V * Hd : 4 * d * d);
     w.scratch = take(64 * big);
+    w.splitk = take(8 * Hd * Hd);
     w.lossp = take(TRAIN_LOSS_BLOCKS);
     w.total = o;
     return w;
@@ -1010,12 +1012,22 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = launch_colsum(ws + w.dh2, Hd, rows, w.nz_rows, Hd, scr, G + sl.f1_b, st)) return rc;
     if (int rc = launch_transpose(ws + w.dh2, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
     if (int rc = launch_transpose(ws + w.h1, rows_pad, Hd, Hd, ws + w.T2, rows_pad, rows_pad, st)) return rc;
-    if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.T1, ws + w.T2, nullptr, G + sl.f1_w, nullptr, Hd, Hd, (int)rows_pad, (int)rows_pad, Hd, Hd, st)) return rc;   // dW2 = dH2^T H1
+    // weight gradients reduce over the rows: few output tiles, long K -> split K so that the grid fills the chip
+    auto wgrad_gemm = [&](const float *At, const float *Bt, int Mo, int No, float *dst) -> int {
+        int split = 1;
+        while (split < 8 && (Mo / GEMM_BM) * (No / GEMM_BN) * split < 512 && (rows_pad / GEMM_BK) % (2 * split) == 0) split *= 2;
+        if (split == 1) return launch_gemm_t<ACT_NONE, 3>(At, Bt, nullptr, dst, nullptr, Mo, No, (int)rows_pad, (int)rows_pad, No, No, st);
+        if (int rc = launch_gemm_t<ACT_NONE, 4>(At, Bt, nullptr, ws + w.splitk, nullptr, Mo, No, (int)rows_pad, (int)rows_pad, No, No, st, split)) return rc;
+        const size_t n = (size_t)Mo * No;
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, ws + w.splitk, split, n, n, dst, 1.0f);
+        return hipGetLastError() == hipSuccess ? 0 : fail(DNAG_E_HIP, "reduce_parts_kernel launch failed");
+    };
+    if (int rc = wgrad_gemm(ws + w.T1, ws + w.T2, Hd, Hd, G + sl.f1_w)) return rc;   // dW2 = dH2^T H1
     if (int rc = launch_gemm_t<ACT_MUL_ELUGRAD, 3>(ws + w.dh2, P + tl.f1T, nullptr, ws + w.dh1, ws + w.h1, rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
     if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, st)) return rc;
     if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
     if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, st)) return rc;
-    if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.T1, ws + w.T2, nullptr, G + sl.f0_w, nullptr, Hd, F, (int)rows_pad, (int)rows_pad, F, F, st)) return rc;     // dW1 = dH1^T concat
+    if (int rc = wgrad_gemm(ws + w.T1, ws + w.T2, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
     if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.dh1, P + tl.f0T, nullptr, ws + w.dconcat, nullptr, rows_pad, F, Hd, Hd, F, F, st)) return rc;
     // ---- 5. encoder backward -----------------------------------------------------------------------------------------
     {

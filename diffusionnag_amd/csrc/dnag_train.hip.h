@@ -928,13 +928,28 @@ __global__ __launch_bounds__(256) void train_unfold_layers_kernel(const float *_
     }
 }
 
-// Philox keep masks: keep[e] = uniform(seed, e) >= p
+// Philox keep masks: one Philox4x32-10 block yields eight 16-bit uniforms -> eight keep bytes
+// (keep = u16 >= p * 65536; the rate is exact to 2^-16).
 __global__ void dropout_fill_kernel(uint8_t *keep, size_t n, float p, uint64_t seed) {
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+    const size_t ngroups = (n + 7) / 8;
+    for (size_t gi = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (size_t)gridDim.x * blockDim.x) {
         uint32_t r[4];
-        const uint64_t blk = e >> 2;
-        philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), 0xd509u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-        const float u = (float)(r[e & 3] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
-        keep[e] = u >= p ? 1 : 0;
+        philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), 0xd509u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+        uint8_t k[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            k[2 * i] = (r[i] & 0xffffu) >= thr ? 1 : 0;
+            k[2 * i + 1] = (r[i] >> 16) >= thr ? 1 : 0;
+        }
+        const size_t e0 = gi * 8;
+        if (e0 + 8 <= n && (reinterpret_cast<uintptr_t>(keep + e0) & 7) == 0) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v |= (uint64_t)k[i] << (8 * i);
+            *reinterpret_cast<uint64_t *>(keep + e0) = v;
+        } else {
+            for (int i = 0; i < 8 && e0 + i < n; ++i) keep[e0 + i] = k[i];
+        }
     }
 }

@@ -26,15 +26,14 @@ def make_model(seed=0):
     return m
 
 
-ATOL = 2e-7   # gradients that are zero analytically (the key bias: softmax is shift invariant) are fp32 noise
-
-
-def rel_err(a, b):
-    """max|a - b| relative to max|b|, after forgiving ATOL of absolute noise."""
+def rel_err(a, b, floor=0.0):
+    """max|a - b| relative to max|b|.  `floor` = 2e-6 of the largest gradient entry of the whole network is
+    forgiven first: a gradient that is zero analytically (the key bias: softmax is shift invariant) is fp32
+    rounding noise of that size in both implementations."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     assert np.isfinite(a).all()
-    return max(np.abs(a - b).max() - ATOL, 0.0) / (np.abs(b).max() + 1e-30)
+    return max(np.abs(a - b).max() - floor, 0.0) / (np.abs(b).max() + 1e-30)
 
 
 def run_step(model, sde, x, t, z, mask, dropout, train=True, reduce_mean=True):
@@ -69,11 +68,12 @@ def test_dsm_step_against_reference_golden(name):
     norms = np.array([float(params[k].grad.double().norm()) for k in names])
     assert np.abs(norms - g["grad_norms"]).max() <= 1e-4 * np.abs(g["grad_norms"]).max()
     np.testing.assert_allclose(norms, g["grad_norms"], rtol=2e-4, atol=1e-7)
+    floor = 2e-6 * max(np.abs(g[key]).max() for key in g if key.startswith("grad:"))
     for key in g:
         if key.startswith("grad:"):
             k = key[5:]
             got = params[k[:-4]].grad[:8] if k.endswith("[:8]") else params[k].grad
-            e = rel_err(got.cpu().numpy(), g[key])
+            e = rel_err(got.cpu().numpy(), g[key], floor)
             assert e <= 5e-5, f"{key}: {e:.3e}"
 
 
@@ -102,8 +102,9 @@ def test_dsm_step_against_oracle_ragged_batch(sde_kind, B, reduce_mean):
     loss = run_step(model, sde, x, t, z, mask, dropout, reduce_mean=reduce_mean)
     assert abs(float(loss.detach()) - float(want_loss)) <= 1e-5 * abs(float(want_loss))
     worst = ("", 0.0)
+    floor = 2e-6 * max(float(v.abs().max()) for v in want.values())
     for k, prm in model.named_parameters():
-        e = rel_err(prm.grad.cpu().numpy(), want[k].numpy())
+        e = rel_err(prm.grad.cpu().numpy(), want[k].numpy(), floor)
         if e > worst[1]:
             worst = (k, e)
         assert e <= 5e-5, f"{k}: {e:.3e}"
@@ -139,10 +140,11 @@ def test_full_size_batch_properties():
     model = make_model(0)
     l1 = run_step(model, sde, x, t, z, mask, None)
     g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    gmax = max(float(v.abs().max()) for v in g1.values())
     l2 = run_step(model, sde, torch.cat([x, x]), torch.cat([t, t]), torch.cat([z, z]), torch.cat([mask, mask]), None)
     assert abs(float(l1.detach()) - float(l2.detach())) <= 2e-6 * abs(float(l1.detach()))
     for k, p in model.named_parameters():
-        e = rel_err(p.grad.cpu().numpy(), g1[k].cpu().numpy())
+        e = rel_err(p.grad.cpu().numpy(), g1[k].cpu().numpy(), 2e-6 * gmax)
         assert e <= 2e-5, f"{k}: {e:.3e}"
     # Philox dropout
     import ctypes as C
@@ -161,5 +163,5 @@ def test_full_size_batch_properties():
     xx, mm = torch.cat([x, x]).to(DEV), torch.cat([mask, mask]).to(DEV)
     loss = fn(model, (xx, mm, mm))
     loss.backward()
-    assert np.isfinite(float(loss))
+    assert np.isfinite(float(loss.detach()))
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
