@@ -818,8 +818,11 @@ struct TrainWs {
     size_t packed, temb, save_e, save_pre, dpre, dtau, xt, concat, h1, h2, out, dout, dh2, dh1, dconcat, T1, T2;
     size_t sv_h, sv_h1, sv_qkv, sv_f, part, gsum, scratch, splitk, lossp, total;
 };
-#define TRAIN_G 8
 #define TRAIN_LOSS_BLOCKS 128
+// graphs per workgroup of the encoder BACKWARD: 8 (64 rows, best MFMA tile reuse) once that fills the chip, else 4
+// (32 rows: twice the workgroups at 2/3 of the latency; measured 1077 -> 712 us at B = 1024).  The forward keeps 8:
+// its latency is set by the weight-fragment loads, which do not shrink with the rows (496 us at G = 8, 589 at G = 4).
+static int train_g(int batch) { return batch >= 2048 ? 8 : 4; }
 
 static TrainWs train_ws(const dnag_cate_dims &c, int batch) {
     TrainWs w;
@@ -828,7 +831,7 @@ static TrainWs train_ws(const dnag_cate_dims &c, int batch) {
     const size_t N = c.max_node, V = c.n_vocab, d = c.d_model, dff = c.d_ff, L = c.n_layers, F = tl.enc.F, Hd = tl.enc.Hd;
     w.rows = (size_t)batch * N;
     w.rows_pad = up(w.rows, GEMM_BM);
-    w.nblk_enc = (batch + TRAIN_G - 1) / TRAIN_G;
+    w.nblk_enc = (batch + train_g(batch) - 1) / train_g(batch);
     w.nz_rows = (int)((w.rows + 127) / 128 < 64 ? (w.rows + 127) / 128 : 64);
     w.nz_b = (batch + 15) / 16 < 64 ? (batch + 15) / 16 : 64;
     size_t o = 0;
@@ -915,6 +918,41 @@ static int launch_transpose(const float *in, size_t rows, int cols, int ld_in, f
     return 0;
 }
 
+template <int G>
+static int launch_train_encoder(bool drop, int nblk, const float *P, const CateLayout &e, const float *xt, const float *temb, const float *mask,
+                                int mstride, float *concat, int B, const EncSave &sv, const DropMasks &dm, hipStream_t st) {
+    typedef EncGeom<8, G, 128> Ge;
+    const size_t lds = Ge::lds_floats * sizeof(float);
+    auto k_drop = encoder_kernel<8, 7, G, 8, 128, true, true, true>;
+    auto k_nodrop = encoder_kernel<8, 7, G, 8, 128, true, true, false>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_drop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nodrop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(drop ? k_drop : k_nodrop, dim3(nblk), dim3(256), lds, st, P, e, xt, temb, 1, mask, mstride, concat, (float *)nullptr, B, 0, sv, dm);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+template <int G>
+static int launch_train_enc_bwd(int nblk, const float *P, const TrainLayout &tl, const EncSave &sv, const float *xt, const float *dconcat,
+                                const float *mask, int mstride, const DropMasks &dm, float *part, const GradLayout &gl, float *dtau, int B,
+                                hipStream_t st) {
+    typedef TrbGeom<8, G, 8, 128> Ge;
+    const size_t lds = Ge::lds_floats * sizeof(float);
+    auto kern = cate_enc_bwd_kernel<8, 7, G, 8, 128>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, tl, sv, xt, dconcat, mask, mstride, dm, part, gl, dtau, B);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (!p) return fail(DNAG_E_ARG, "args is NULL");
     if (int rc = check_train_dims(p->cate_dims)) return rc;
@@ -968,21 +1006,8 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     DropMasks dm;
     memset(&dm, 0, sizeof(dm));
     if (drop) { dm.keep = p->keep; dm.keep_prob = 1.0f - p->dropout_p; dm.rows = rows; dm.per_layer = cd.n_head * N + 2 * d + dff; }
-    {
-        typedef EncGeom<8, TRAIN_G, 128> Ge;
-        const size_t lds = Ge::lds_floats * sizeof(float);
-        auto k_drop = encoder_kernel<8, 7, TRAIN_G, 8, 128, true, true, true>;
-        auto k_nodrop = encoder_kernel<8, 7, TRAIN_G, 8, 128, true, true, false>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_drop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nodrop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(drop ? k_drop : k_nodrop, dim3(w.nblk_enc), dim3(256), lds, st, P, e, ws + w.xt, ws + w.temb, 1, p->mask,
-                           p->mask_stride ? 1 : 0, ws + w.concat, (float *)nullptr, B, 0, sv, dm);
-        LAUNCH_CHECK();
-    }
+    if (int rc = launch_train_encoder<8>(drop, (B + 7) / 8, P, e, ws + w.xt, ws + w.temb, p->mask, p->mask_stride ? 1 : 0, ws + w.concat, B, sv, dm, st))
+        return rc;
     // ---- 3. head MLP and loss ------------------------------------------------------------------------------------
     if (int rc = launch_gemm_t<ACT_ELU, 3>(ws + w.concat, P + e.f0_w, P + e.f0_b, ws + w.h1, nullptr, rows_pad, Hd, F, F, Hd, Hd, st)) return rc;
     if (int rc = launch_gemm_t<ACT_ELU, 3>(ws + w.h1, P + e.f1_w, P + e.f1_b, ws + w.h2, nullptr, rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
@@ -1030,19 +1055,9 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = wgrad_gemm(ws + w.T1, ws + w.T2, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
     if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.dh1, P + tl.f0T, nullptr, ws + w.dconcat, nullptr, rows_pad, F, Hd, Hd, F, F, st)) return rc;
     // ---- 5. encoder backward -----------------------------------------------------------------------------------------
-    {
-        typedef TrbGeom<8, TRAIN_G, 8, 128> Ge;
-        const size_t lds = Ge::lds_floats * sizeof(float);
-        auto kern = cate_enc_bwd_kernel<8, 7, TRAIN_G, 8, 128>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(w.nblk_enc), dim3(256), lds, st, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm,
-                           ws + w.part, gl, ws + w.dtau, B);
-        LAUNCH_CHECK();
-    }
+    if (int rc = train_g(B) == 8 ? launch_train_enc_bwd<8>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st)
+                                 : launch_train_enc_bwd<4>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st))
+        return rc;
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((gl.total + 255) / 256)), dim3(256), 0, st, ws + w.part, w.nblk_enc, gl.total, gl.total,
                        ws + w.gsum, 1.0f);
     LAUNCH_CHECK();

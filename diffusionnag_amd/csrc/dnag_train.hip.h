@@ -404,15 +404,16 @@ struct TrbGeom {
     static constexpr int FS = DFF + 4;
     static constexpr int NIT = (G * H * N + 255) / 256;        // attention items per thread
     static constexpr size_t lds_floats = 4 * (size_t)RP * HS + (size_t)RP * QS + 2 * (size_t)G * H * N * N + (size_t)G * N * N;
-    static_assert(RP == 64, "the weight-gradient tiles reduce over exactly 64 rows");
+    static_assert(RP == 64 || RP == 32, "the weight-gradient tiles reduce over 32 or 64 rows");
     static_assert(RP * FS <= RP * QS, "FFN hidden aliases the q|k|v buffer");
     static_assert(2 * G * H * N * N >= 2 * 16 * DNAG_D, "norm-gradient scratch aliases the probability buffers");
     static_assert(R * 16 <= RP * QS, "staged x aliases the q|k|v buffer");
 };
 
-// acc[reg] = sum_k Y[k][m0 + acc_row(reg, h)] * X[k][n0 + r] over the 64 rows k of two LDS buffers
+// acc[reg] = sum_k Y[k][m0 + acc_row(reg, h)] * X[k][n0 + r] over the KR rows k of two LDS buffers
 // (strides sy, sx == 4 mod 64).  Lane half h takes rows {16 c + 8 h + i}: the two halves of a ds_read_b32
 // hit disjoint bank halves.
+template <int KR>
 __device__ __forceinline__ f32x16 wgrad_tile(const float *Y, int sy, int m0, const float *X, int sx, int n0) {
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     f32x16 acc;
@@ -421,7 +422,7 @@ __device__ __forceinline__ f32x16 wgrad_tile(const float *Y, int sy, int m0, con
     const float *yp = Y + (8 * h) * sy + m0 + r;
     const float *xp = X + (8 * h) * sx + n0 + r;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int c = 0; c < KR / 16; ++c)
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc = mfma32(yp[(16 * c + i) * sy], xp[(16 * c + i) * sx], acc);
     return acc;
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
         // ---- (c1) dW2 = dY2^T f;  db2 ------------------------------------------------------------------------
         for (int j = wave; j < (D / 32) * (DFF / 32); j += 4) {
             const int mt = j / (DFF / 32), nt = j - mt * (DFF / 32);
-            wgrad_store(GP + gl.l_w2, DFF, mt * 32, nt * 32, wgrad_tile(tmp, HS, mt * 32, fb, FS, nt * 32));
+            wgrad_store(GP + gl.l_w2, DFF, mt * 32, nt * 32, wgrad_tile<RP>(tmp, HS, mt * 32, fb, FS, nt * 32));
         }
         colsum(tmp, HS, D, GP + gl.l_b2);
         __syncthreads();
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
         // ---- (d) dW1' = dF^T u2;  db1';  du2 = dF W1' -> tmp ---------------------------------------------------
         for (int j = wave; j < (DFF / 32) * (D / 32); j += 4) {
             const int mt = j / (D / 32), nt = j - mt * (D / 32);
-            wgrad_store(GP + gl.l_w1, D, mt * 32, nt * 32, wgrad_tile(fb, FS, mt * 32, xh, HS, nt * 32));
+            wgrad_store(GP + gl.l_w1, D, mt * 32, nt * 32, wgrad_tile<RP>(fb, FS, mt * 32, xh, HS, nt * 32));
         }
         colsum(fb, FS, DFF, GP + gl.l_b1);
         {
@@ -806,11 +807,11 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
         for (int j = wave; j < (D / 32) * (D / 32) + (3 * D / 32) * (D / 32); j += 4) {
             if (j < (D / 32) * (D / 32)) {
                 const int mt = j / (D / 32), nt = j - mt * (D / 32);
-                wgrad_store(GP + gl.l_wo, D, mt * 32, nt * 32, wgrad_tile(tmp, HS, mt * 32, xh, HS, nt * 32));
+                wgrad_store(GP + gl.l_wo, D, mt * 32, nt * 32, wgrad_tile<RP>(tmp, HS, mt * 32, xh, HS, nt * 32));
             } else {
                 const int jj = j - (D / 32) * (D / 32);
                 const int mt = jj / (D / 32), nt = jj - mt * (D / 32);
-                wgrad_store(GP + gl.l_wqkv, D, mt * 32, nt * 32, wgrad_tile(qb, QS, mt * 32, ob, HS, nt * 32));
+                wgrad_store(GP + gl.l_wqkv, D, mt * 32, nt * 32, wgrad_tile<RP>(qb, QS, mt * 32, ob, HS, nt * 32));
             }
         }
         colsum(tmp, HS, D, GP + gl.l_bo);
@@ -903,22 +904,30 @@ __global__ __launch_bounds__(256) void train_unfold_layers_kernel(const float *_
         j -= D;
         if (j < 2 * D) {            // self_attn.norm: gamma (j < D), beta
             const size_t k = j < D ? j : j - D;
-            float acc = 0.f;
-            for (size_t r = 0; r < 3 * D; ++r) {
-                const size_t which = r / D, rr = r - which * D;
-                const float w = SL[(which == 0 ? sl.s_wq : which == 1 ? sl.s_wk : sl.s_wv) + rr * D + k];
-                acc = fmaf(j < D ? GL[gl.l_wqkv + r * D + k] : GL[gl.l_bqkv + r], w, acc);
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};     // four independent chains: the loads of a chain overlap
+            for (size_t r0 = 0; r0 < 3 * D; r0 += 4) {
+#pragma unroll
+                for (size_t u = 0; u < 4; ++u) {
+                    const size_t r = r0 + u, which = r / D, rr = r - which * D;
+                    const float w = SL[(which == 0 ? sl.s_wq : which == 1 ? sl.s_wk : sl.s_wv) + rr * D + k];
+                    acc4[u] = fmaf(j < D ? GL[gl.l_wqkv + r * D + k] : GL[gl.l_bqkv + r], w, acc4[u]);
+                }
             }
-            OL[(j < D ? sl.s_ln1g : sl.s_ln1b) + k] = acc;
+            OL[(j < D ? sl.s_ln1g : sl.s_ln1b) + k] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             continue;
         }
         j -= 2 * D;
         if (j < 2 * D) {            // feed_forward.norm
             const size_t k = j < D ? j : j - D;
-            float acc = 0.f;
-            for (size_t r = 0; r < DFF; ++r)
-                acc = fmaf(j < D ? GL[gl.l_w1 + r * D + k] : GL[gl.l_b1 + r], SL[sl.s_w1 + r * D + k], acc);
-            OL[(j < D ? sl.s_ln2g : sl.s_ln2b) + k] = acc;
+            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (size_t r0 = 0; r0 < DFF; r0 += 4) {
+#pragma unroll
+                for (size_t u = 0; u < 4; ++u) {
+                    const size_t r = r0 + u;
+                    acc4[u] = fmaf(j < D ? GL[gl.l_w1 + r * D + k] : GL[gl.l_b1 + r], SL[sl.s_w1 + r * D + k], acc4[u]);
+                }
+            }
+            OL[(j < D ? sl.s_ln2g : sl.s_ln2b) + k] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
             continue;
         }
         j -= 2 * D;
