@@ -29,6 +29,7 @@ struct CateLayout {
     size_t l_wqkv, l_bqkv, l_wo, l_bo, l_w1, l_b1, l_w2, l_b2, l_ong, l_onb;  // relative to a layer base
     size_t f0_w, f0_b, f1_w, f1_b, f2_w, f2_b;  // final.linears.{0,1,2}
     size_t pe, freq;              // [N][d], [d/2]
+    size_t f0_s, f1_s;            // final.linears.{0,1} weights as split-pair fp16 rows (dnag_gemm16.hip.h), same sizes
     size_t total;
     int F, Hd;                    // F = L*d (concat width), Hd = 2F (head hidden)
 };
@@ -68,6 +69,8 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
     y.f2_b = o; o += align4(V);
     y.pe = o; o += align4((size_t)y.N * d);
     y.freq = o; o += align4(d / 2);
+    y.f0_s = o; o += Hd * F;
+    y.f1_s = o; o += Hd * Hd;
     y.total = o;
     return y;
 }

@@ -204,7 +204,8 @@ __device__ __forceinline__ float drop_apply(float v, uint8_t keep, float keep_pr
 
 // x [batch][N][V]; temb [tstride ? batch : 1][64]; mask [mstride ? batch : 1][N][N];
 // concat [rows_pad][L*64] (row = graph*N + node); attn0 [batch][H][N][N] or null.
-template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false, bool DROP = false>
+// SPLIT: concat rows are written as split-pair fp16 rows (dnag_gemm16.hip.h) for the fp16-MFMA head GEMM.
+template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false, bool DROP = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict__ P, const CateLayout lay,
                                                          const float *__restrict__ x, const float *__restrict__ temb,
                                                          int tstride, const float *__restrict__ mask, int mstride,
@@ -444,6 +445,20 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     v4f o4;
                     o4.x = v.x * s * g4.x + b4.x; o4.y = v.y * s * g4.y + b4.y;
                     o4.z = v.z * s * g4.z + b4.z; o4.w = v.w * s * g4.w + b4.w;
+                    if constexpr (SPLIT) {
+                        typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                        h4_t hi4, lo4;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const _Float16 hi = (_Float16)o4[e];
+                            hi4[e] = hi;
+                            lo4[e] = (_Float16)((o4[e] - (float)hi) * 2048.0f);
+                        }
+                        const int k = l * D + 4 * sub;
+                        _Float16 *dst = reinterpret_cast<_Float16 *>(concat + ((size_t)g0 * N + r) * lay.F) + (k >> 3) * 16 + (k & 7);
+                        *reinterpret_cast<h4_t *>(dst) = hi4;
+                        *reinterpret_cast<h4_t *>(dst + 8) = lo4;
+                    } else
                     *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + r) * lay.F + l * D + 4 * sub) = o4;
                 }
             }

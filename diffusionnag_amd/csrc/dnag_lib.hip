@@ -13,6 +13,7 @@
 #include "dnag_common.h"
 #include "dnag_encoder.hip.h"
 #include "dnag_head.hip.h"
+#include "dnag_gemm16.hip.h"
 #include "dnag_predictor.hip.h"
 #include "dnag_predcate.hip.h"
 #include "dnag_train.hip.h"
@@ -148,6 +149,8 @@ static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *
     take(y.f0_w, Hd * F); take(y.f0_b, Hd);
     take(y.f1_w, Hd * Hd); take(y.f1_b, Hd);
     take(y.f2_w, V * Hd); take(y.f2_b, V);
+    split_pack(out + y.f0_w, Hd, F, out + y.f0_s);
+    split_pack(out + y.f1_w, Hd, Hd, out + y.f1_s);
     if (o != dnag_cate_state_floats(&c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_cate_state_floats(&c));
     if (pe) memcpy(out + y.pe, pe, (size_t)y.N * d * sizeof(float));
     memcpy(out + y.freq, freq, (d / 2) * sizeof(float));
@@ -459,10 +462,13 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
         }
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev0[slot], st));
-    // two instantiations so that profiles list final.linears.0 (K = F) and final.linears.1 (K = 2F) apart
-    int rc = timed ? launch_gemm_t<ACT_ELU, 1>(A, W, bias, C, nullptr, M, Nout, K, K, Nout, Nout, st)
-                   : launch_gemm_t<ACT_ELU, 0>(A, W, bias, C, nullptr, M, Nout, K, K, Nout, Nout, st);
-    if (rc) return rc;
+    // split-arithmetic fp16 MFMA GEMMs (dnag_gemm16.hip.h): final.linears.0 (K = F) reads the encoder's split-pair
+    // concat and writes split-pair rows; final.linears.1 (K = 2F, the timed one) writes fp32 for the exit kernel
+    if (M % GEMM_BM || Nout % GEMM_BN || K % GEMM_BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
+    const int grid = (int)(M / GEMM_BM) * (Nout / GEMM_BN);
+    if (timed) hipLaunchKernelGGL((gemm_split_kernel<ACT_ELU, false, 1>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
+    else hipLaunchKernelGGL((gemm_split_kernel<ACT_ELU, true, 0>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
+    LAUNCH_CHECK();
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
     return 0;
 }
@@ -480,7 +486,7 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
                             const float *mask, int mstride, float *concat, float *attn0, int batch, hipStream_t st) {
     typedef EncGeom<N, G, 128> Ge;
     const size_t lds = Ge::lds_floats * sizeof(float);
-    auto kern = encoder_kernel<N, V, G, 8, 128, true>;
+    auto kern = encoder_kernel<N, V, G, 8, 128, true, false, false, true>;   // concat in split-pair rows
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -535,8 +541,8 @@ static int run_score_body(const dnag_cate_dims &c, const CateLayout &lay, const 
                           int tstride, const float *mask, int mstride, float *ws, const WsLayout &w, float *attn0, int batch,
                           hipStream_t st) {
     if (int rc = launch_encoder(c, lay, P, x, temb, tstride, mask, mstride, ws + w.concat, attn0, batch, st)) return rc;
-    if (int rc = launch_gemm(ws + w.concat, P + lay.f0_w, P + lay.f0_b, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st)) return rc;
-    if (int rc = launch_gemm(ws + w.h1, P + lay.f1_w, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st)) return rc;
+    if (int rc = launch_gemm(ws + w.concat, P + lay.f0_s, P + lay.f0_b, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st)) return rc;
+    if (int rc = launch_gemm(ws + w.h1, P + lay.f1_s, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st)) return rc;
     return 0;
 }
 
@@ -559,8 +565,10 @@ extern "C" int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, c
     memset(&a, 0, sizeof(a));
     a.mode = EXIT_FORWARD; a.batch = batch; a.out = out;
     if (int rc = launch_exit(*d, lay, packed, ws + w.h2, a, st)) return rc;
-    if (concat_out)
-        HIP_TRY(hipMemcpyAsync(concat_out, ws + w.concat, w.rows * lay.F * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (concat_out) {   // the workspace holds split-pair rows; hand back plain fp32
+        hipLaunchKernelGGL(unsplit_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, lay.F);
+        LAUNCH_CHECK();
+    }
     return 0;
 }
 
