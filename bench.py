@@ -32,12 +32,18 @@ from diffusionnag_amd.specs import CateDims, PredictorCateDims, PredictorDims  #
 # algorithmic FLOPs (2 per MAC) of one guided sample (2000 score evaluations + guidance gradients): SURVEY.md section 8d
 FLOP_PER_SAMPLE = {"nb201": 136.3e9, "ofa": 345.4e9}
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: BF16/F16 ~2.5 PF dense (a bare v_mfma_f32_32x32x16_f16 loop sustains ~1950 on this
+                                  # chip, tests/micro/gemm16_bench.hip)
+# The dominant kernel computes in split arithmetic (diffusionnag_amd/csrc/dnag_gemm16.hip.h): every fp32-accurate
+# product costs THREE fp16 MFMAs, so `achieved` (ALGORITHMIC flops / time, as the contract defines it) can reach at
+# most a third of the fp16 peak; `mfma_issued_*` gives the matrix-core utilisation proper.
+SPLIT_MFMA_PER_PRODUCT = 3
 # Fabric-side bytes of ONE launch of the dominant kernel (final.linears.1 at B=4096, NB201) from PMC counters:
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as the guide's HBM
-# section prescribes for gfx950 (profiles/r01c_pmc_traffic.json: 1.238 GB read + 0.201 GB written; algorithmic
-# bytes 0.412 GB -- the excess is the 9.4 MB weight matrix re-read from the Infinity Cache by every row panel).
-# Counters cannot be collected inside this process, so the figure is quoted only for the shape it was measured on.
-PMC_TRAFFIC_BYTES = {("nb201", 4096): 1439538758}
+# section prescribes for gfx950 (profiles/r01f_pmc_traffic.json: 0.461 GB read + 0.201 GB written; algorithmic
+# bytes 0.412 GB).  Counters cannot be collected inside this process, so the figure is quoted only for the shape it
+# was measured on.
+PMC_TRAFFIC_BYTES = {("nb201", 4096): 662525952}
 
 
 class Cfg(dict):
@@ -234,7 +240,8 @@ def main():
         line = {
             "metric": "guided arch samples/sec (full reverse SDE), " + ("OFA" if ofa else "NB201"), "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (head GEMMs: f16 hi/lo pairs, 22 significant bits, f32 accumulation)", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[3]: MobileNetV3/OFA 20-node graphs, guided sampling (MetaPredictorCATE gradient), "
                                     f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
                                     "snr 0.16, classifier_scale 1e3, chain mask, random-init weights (seeded), Philox noise on device")
@@ -245,10 +252,15 @@ def main():
                                     "Philox noise on device"),
                        "batch_per_gpu": B, "global_batch": total, "pc_steps": a.sde_steps,
                        "score_evals_per_sample": 2 * a.sde_steps, "parallelism": f"batch-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_bias_act_kernel<1,1> (final.linears.1, M x 1536 x 1536, fp32 MFMA)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": PMC_TRAFFIC_BYTES.get((a.workload, B)),
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01c_pmc_traffic.json)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_split_kernel<1,false,1> (final.linears.1, M x 1536 x 1536, fp32-accurate "
+                                                    "hi/lo split on v_mfma_f32_32x32x16_f16, 3 MFMAs per product)",
+                         "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F16_MFMA_TFLOPS,
+                         "mfma_issued_tflops": achieved * SPLIT_MFMA_PER_PRODUCT,
+                         "mfma_issued_frac": achieved * SPLIT_MFMA_PER_PRODUCT / PEAK_F16_MFMA_TFLOPS,
+                         "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "traffic": PMC_TRAFFIC_BYTES.get((a.workload, B)),
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01f_pmc_traffic.json)",
                          "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value},
             "whole_path_tflops": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world,
             "whole_path_frac_of_f32_mfma_peak": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,

@@ -450,9 +450,10 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         h4_t hi4, lo4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const _Float16 hi = (_Float16)o4[e];
+                            const float sv16 = o4[e] * 16.0f;           // SPLIT_SA (dnag_gemm16.hip.h)
+                            const _Float16 hi = (_Float16)sv16;
                             hi4[e] = hi;
-                            lo4[e] = (_Float16)((o4[e] - (float)hi) * 2048.0f);
+                            lo4[e] = (_Float16)(sv16 - (float)hi);
                         }
                         const int k = l * D + 4 * sub;
                         _Float16 *dst = reinterpret_cast<_Float16 *>(concat + ((size_t)g0 * N + r) * lay.F) + (k >> 3) * 16 + (k & 7);

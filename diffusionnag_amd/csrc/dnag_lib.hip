@@ -350,7 +350,7 @@ static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int 
     const size_t N = c.max_node, V = c.n_vocab, F = (size_t)c.n_layers * c.d_model, Hd = 2 * F;
     const size_t nt = (size_t)(n_steps > batch ? n_steps : batch);
     w.rows = (size_t)batch * N;
-    w.rows_pad = up(w.rows, GEMM_BM);
+    w.rows_pad = up(w.rows, 256);   // the split GEMM runs 256-row tiles
     w.nblk_exit = (batch + exit_gf(c) - 1) / exit_gf(c);
     size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += up(n, 64); return at; };
@@ -464,10 +464,18 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev0[slot], st));
     // split-arithmetic fp16 MFMA GEMMs (dnag_gemm16.hip.h): final.linears.0 (K = F) reads the encoder's split-pair
     // concat and writes split-pair rows; final.linears.1 (K = 2F, the timed one) writes fp32 for the exit kernel
-    if (M % GEMM_BM || Nout % GEMM_BN || K % GEMM_BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
-    const int grid = (int)(M / GEMM_BM) * (Nout / GEMM_BN);
-    if (timed) hipLaunchKernelGGL((gemm_split_kernel<ACT_ELU, false, 1>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
-    else hipLaunchKernelGGL((gemm_split_kernel<ACT_ELU, true, 0>), dim3(grid), dim3(256), 0, st, A, W, bias, C, (int)M, Nout, K);
+    typedef SplitGeom Ge;
+    if (M % Ge::BM || Nout % Ge::BN || K % GEMM_BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
+    const int grid = (int)(M / Ge::BM) * (Nout / Ge::BN);
+    auto k1 = gemm_split_kernel<ACT_ELU, false, 1>;
+    auto k0 = gemm_split_kernel<ACT_ELU, true, 0>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(timed ? k1 : k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K);
     LAUNCH_CHECK();
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
     return 0;

@@ -22,6 +22,11 @@ case $step in
           tail -1 gpurun_out/prof.log ;;
   proftrain) run 200 prof_train.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python3 bench.py --workload train --steps 20
           tail -1 gpurun_out/prof_train.log ;;
+  pmc)    # HBM/fabric traffic of the per-evaluation kernels: separate passes, as the guide's HBM section prescribes
+          for c in FETCH_SIZE WRITE_SIZE; do
+            run 150 pmc_$c.log timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_$c -o k -- python3 tests/gpu_kern_times.py
+            python3 tests/pmc_summary.py gpurun_out/pmc_$c/k_counter_collection.csv > gpurun_out/pmc_$c.txt 2>&1; cat gpurun_out/pmc_$c.txt
+          done ;;
   smoke)  run 200 smoke.log python __graft_entry__.py smoke; tail -2 gpurun_out/smoke.log ;;
 esac
 done

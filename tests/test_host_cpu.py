@@ -106,9 +106,18 @@ def test_cate_pack_folds_layernorm_into_linear():
     f0 = layer0 + 12 * stride
     assert np.array_equal(packed[f0: f0 + 1536 * 768].astype(np.float32), sd["final.linears.0.weight"].numpy().ravel())
     # derived tables = the oracle's restatement of the reference constructors
-    tail = packed[-(8 * 64 + 32):]
+    n_split = 1536 * 768 + 1536 * 1536                 # split-pair copies of final.linears.{0,1} close the blob
+    tail = packed[-(8 * 64 + 32) - n_split: -n_split]
     assert np.allclose(tail[: 8 * 64], O.positional_table(8, 64, False).numpy().ravel(), atol=0)
     assert np.allclose(tail[8 * 64:], _cate.timestep_frequencies(64).numpy(), atol=0)
+    # split-pair rows (csrc/dnag_gemm16.hip.h): groups of 8 values = 8 fp16 hi then 8 fp16 lo of 256 w; hi + lo
+    # reproduces the fp32 weight to 22 significant bits
+    raw = model._pack_host(model._state_flat().contiguous()).numpy()[-n_split:]
+    halves = raw[: 1536 * 768].view(np.float16).reshape(1536, 768 // 8, 2, 8).astype(np.float64)
+    w0 = sd["final.linears.0.weight"].double().numpy()
+    rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 768) / 256.0
+    assert np.abs(rec - w0).max() <= 2.0 ** -21 * np.abs(w0).max()
+    assert np.array_equal(halves[:, :, 0, :].reshape(1536, 768), (w0 * 256).astype(np.float16).astype(np.float64))
 
 
 def test_predictor_pack_transposes():
@@ -154,8 +163,9 @@ def test_predictor_cate_pack_layout():
     stride = 3 * D_ * D_ + 3 * D_ + D_ * D_ + D_ + dff * D_ + dff + D_ * dff + D_ + 2 * D_
     f0 = layer0 + L * stride
     assert np.array_equal(packed[f0: f0 + Hd * F], sdp["final.linears.0.weight"].numpy().ravel())
-    enc_total = f0 + Hd * F + Hd + Hd * Hd + Hd + al4(V * Hd) + al4(V) + al4(20 * D_) + al4(D_ // 2)
-    assert not packed[enc_total - al4(D_ // 2) - al4(20 * D_): enc_total - al4(D_ // 2)].any()      # no positional table
+    tab_end = f0 + Hd * F + Hd + Hd * Hd + Hd + al4(V * Hd) + al4(V) + al4(20 * D_) + al4(D_ // 2)
+    assert not packed[tab_end - al4(D_ // 2) - al4(20 * D_): tab_end - al4(D_ // 2)].any()      # no positional table
+    enc_total = tab_end + Hd * F + Hd * Hd          # split-pair copies of final.linears.{0,1} (unused by this surrogate)
     # backward operands of layer 1: Wo^T and W2^T, fragment-major
     per_layer = 32 * 2 * 3 * D_ + 32 * 2 * D_ + 32 * 2 * dff + 32 * D_      # frag_floats(rows, K) = ceil(rows/32)*32*K
     b1 = enc_total + per_layer
