@@ -81,10 +81,16 @@ struct SplitGeom {
 #define SPLIT_DBG 0      // timing ablations of tests/micro/gemm16_bench.hip (results become wrong): 1 no global loads,
 #endif                   // 2 no LDS stores, 4 no MFMAs, 8 hi*hi MFMAs only, 16 no barriers in the loop
 
-template <int ACT, bool OUT_SPLIT, int TAG>
+// FUSE_V > 0 (final.linears.1 of the score network): the MFMA operands swap roles, so that a lane holds ONE row of
+// the batch and its registers 16 output columns, and the epilogue applies final.linears.2 (W3 [FUSE_V][Nout],
+// cate.py:55-73) to the ELU output in registers: parts[tn][row][v] = sum over this block's 256 columns of
+// elu(...)[row][col] W3[v][col], summed in a fixed order (lane, lane half, the 4 waves along N).  The 1536-wide
+// hidden activation never reaches HBM; the exit kernel adds the Nout / 256 partial sums and the bias.  C is unused.
+template <int ACT, bool OUT_SPLIT, int TAG, int FUSE_V = 0>
 __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ C,
-                                                            int M, int Nout, int K) {
+                                                            int M, int Nout, int K, const float *__restrict__ W3 = nullptr,
+                                                            float *__restrict__ parts = nullptr) {
     typedef SplitGeom Ge;
     constexpr int BM = Ge::BM, BN = Ge::BN, RPP = Ge::RPP, NPA = Ge::NPA, NPB = Ge::NPB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,6 +170,14 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
                 acc[i][0][0] += (float)ah[i][0] + (float)al[i][0] + (float)bh[CS][0][0] + (float)bl[CS][0][0] + (float)bh[CS][1][0] + (float)bl[CS][1][0];
             } else {
                 // the three MFMAs of one accumulator are interleaved with the other tile's: no back-to-back dependency
+                if constexpr (FUSE_V > 0) {     // D[n][m]: lane <-> batch row, registers <-> output columns
+                    acc[i][0] = mfma16(bh[CS][0], ah[i], acc[i][0]);
+                    acc[i][1] = mfma16(bh[CS][1], ah[i], acc[i][1]);
+                    acc[i][0] = mfma16(bl[CS][0], ah[i], acc[i][0]);
+                    acc[i][1] = mfma16(bl[CS][1], ah[i], acc[i][1]);
+                    acc[i][0] = mfma16(bh[CS][0], al[i], acc[i][0]);
+                    acc[i][1] = mfma16(bh[CS][1], al[i], acc[i][1]);
+                } else {
                 acc[i][0] = mfma16(ah[i], bh[CS][0], acc[i][0]);
                 acc[i][1] = mfma16(ah[i], bh[CS][1], acc[i][1]);
                 if (!(SPLIT_DBG & 8)) {
@@ -171,6 +185,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
                     acc[i][1] = mfma16(ah[i], bl[CS][1], acc[i][1]);
                     acc[i][0] = mfma16(al[i], bh[CS][0], acc[i][0]);
                     acc[i][1] = mfma16(al[i], bh[CS][1], acc[i][1]);
+                }
                 }
             }
             if (more && !(SPLIT_DBG & 32)) {
@@ -193,6 +208,53 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
         mfma_step(S1{}, S0{}, kt + 1 < KT, cur ^ 1, 0);
     }
 
+    if constexpr (FUSE_V > 0) {
+        constexpr int V = FUSE_V;
+        __syncthreads();                            // every wave is done with the staged tiles: LDS is free
+        float *w3s = smem;                          // [V][BN] slice of W3
+        float *b1s = w3s + V * BN;                  // [BN] slice of the bias
+        float *red = b1s + BN;                      // [4][BM][V] per-wave-column partial sums
+        for (int i = tid; i < V * BN; i += 512) { const int v = i / BN, c = i - v * BN; w3s[i] = W3[(size_t)v * Nout + tn * BN + c]; }
+        for (int i = tid; i < BN; i += 512) b1s[i] = bias ? bias[tn * BN + i] : 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float part[V];
+#pragma unroll
+            for (int v = 0; v < V; ++v) part[v] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c0 = wn * 64 + t * 32 + 8 * q + 4 * h;        // columns of registers 4q .. 4q+3
+                    const v4f b4 = *reinterpret_cast<const v4f *>(b1s + c0);
+                    float hv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float x = fmaf(acc[i][t][4 * q + u], SPLIT_OUT_INV, b4[u]);
+                        if (ACT == ACT_ELU) x = x > 0.f ? x : __expf(x) - 1.0f;
+                        hv[u] = x;
+                    }
+#pragma unroll
+                    for (int v = 0; v < V; ++v) {
+                        const v4f w4 = *reinterpret_cast<const v4f *>(w3s + v * BN + c0);
+                        part[v] = fmaf(hv[0], w4.x, part[v]); part[v] = fmaf(hv[1], w4.y, part[v]);
+                        part[v] = fmaf(hv[2], w4.z, part[v]); part[v] = fmaf(hv[3], w4.w, part[v]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // keep the W3 reads of later columns from piling up in registers
+                }
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+                part[v] += __shfl_xor(part[v], 32);                        // the other lane half holds the other columns
+                if (h == 0) red[(wn * BM + wm * 128 + i * 32 + r) * V + v] = part[v];
+            }
+        }
+        __syncthreads();
+        float *dst = parts + ((size_t)tn * M + (size_t)tm * BM) * V;
+        for (int i = tid; i < BM * V; i += 512)
+            dst[i] = (red[i] + red[BM * V + i]) + (red[2 * BM * V + i] + red[3 * BM * V + i]);
+        return;
+    }
     // epilogue: scale back, bias, activation; fp32 rows or split-pair rows
 #pragma unroll
     for (int j = 0; j < 2; ++j) {

@@ -171,6 +171,11 @@ struct ExitArgs {
     uint32_t draw;
     // optional records
     float *rec_score, *rec_total, *rec_a, *rec_b;   // predictor: rec_a = x_mean, rec_b = x_pred
+    // final.linears.2 already applied by the fused GEMM epilogue (dnag_gemm16.hip.h): nparts partial sums
+    // [nparts][rows_pad][V], part_stride floats apart; null: compute it here from H2
+    const float *parts;
+    int nparts;
+    size_t part_stride;
 };
 
 // H2 [rows_pad][K]; W3 [V][K]; b3 [V].  One block = GF graphs = GF*N <= 64 rows.
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
     for (int v = 0; v < V; ++v) acc[v] = 0.f;
 
     const int lrow = tid >> 4, lk = (tid & 15) * 4;
-    for (int k0 = 0; k0 < K; k0 += 64) {
+    for (int k0 = 0; k0 < (a.parts ? 0 : K); k0 += 64) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int rr = lrow + 16 * p;
@@ -231,8 +236,15 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
         const bool valid = rr < R && (blockIdx.x * GF + g) < a.batch;
         float total = 0.f, noise = 0.f;
         if (valid) {
-            const float val = ((red[0][rr][v] + red[1][rr][v]) + (red[2][rr][v] + red[3][rr][v])) + b3[v];
             const size_t e = (size_t)(row0 + rr) * V + v;
+            float val;
+            if (a.parts) {
+                val = a.parts[e];
+                for (int p = 1; p < a.nparts; ++p) val += a.parts[(size_t)p * a.part_stride + e];
+                val += b3[v];
+            } else {
+                val = ((red[0][rr][v] + red[1][rr][v]) + (red[2][rr][v] + red[3][rr][v])) + b3[v];
+            }
             if (a.mode == EXIT_FORWARD) {
                 if (a.out_gstride) a.out[(size_t)(blockIdx.x * GF + g) * a.out_gstride + (rr - g * N) * V + v] = val;
                 else a.out[e] = val;

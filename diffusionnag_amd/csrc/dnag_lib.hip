@@ -451,7 +451,7 @@ static int launch_gemm_t(const float *A, const float *W, const float *bias, floa
 }
 
 static int launch_gemm(const float *A, const float *W, const float *bias, float *C, size_t M, int Nout, int K, bool timed,
-                       size_t real_rows, hipStream_t st) {
+                       size_t real_rows, hipStream_t st, const float *W3 = nullptr, int V = 0) {
     int slot = -1;
     if (timed) {
         std::lock_guard<std::mutex> lk(g_tm_mu);
@@ -467,15 +467,23 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
     typedef SplitGeom Ge;
     if (M % Ge::BM || Nout % Ge::BN || K % GEMM_BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
     const int grid = (int)(M / Ge::BM) * (Nout / Ge::BN);
-    auto k1 = gemm_split_kernel<ACT_ELU, false, 1>;
+    auto k7 = gemm_split_kernel<ACT_ELU, false, 1, 7>;      // final.linears.1 + final.linears.2 fused, NAS-Bench-201
+    auto k9 = gemm_split_kernel<ACT_ELU, false, 1, 9>;      // same, OFA
     auto k0 = gemm_split_kernel<ACT_ELU, true, 0>;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL(timed ? k1 : k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K);
+    if (timed) {
+        if (V != 7 && V != 9) return fail(DNAG_E_ARG, "fused head GEMM is built for 7 or 9 output columns, got %d", V);
+        // C receives the partial sums [Nout / 256][M][V] of final.linears.2
+        hipLaunchKernelGGL(V == 7 ? k7 : k9, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, (float *)nullptr, (int)M, Nout, K, W3, C);
+    } else {
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr);
+    }
     LAUNCH_CHECK();
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
     return 0;
@@ -550,7 +558,8 @@ static int run_score_body(const dnag_cate_dims &c, const CateLayout &lay, const 
                           hipStream_t st) {
     if (int rc = launch_encoder(c, lay, P, x, temb, tstride, mask, mstride, ws + w.concat, attn0, batch, st)) return rc;
     if (int rc = launch_gemm(ws + w.concat, P + lay.f0_s, P + lay.f0_b, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st)) return rc;
-    if (int rc = launch_gemm(ws + w.h1, P + lay.f1_s, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st)) return rc;
+    // final.linears.1 with final.linears.2 fused into its epilogue: ws.h2 receives [Hd / 256][rows_pad][V] partial sums
+    if (int rc = launch_gemm(ws + w.h1, P + lay.f1_s, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st, P + lay.f2_w, lay.V)) return rc;
     return 0;
 }
 
@@ -572,6 +581,7 @@ extern "C" int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, c
     ExitArgs a;
     memset(&a, 0, sizeof(a));
     a.mode = EXIT_FORWARD; a.batch = batch; a.out = out;
+    a.parts = ws + w.h2; a.nparts = lay.Hd / SplitGeom::BN; a.part_stride = w.rows_pad * (size_t)lay.V;
     if (int rc = launch_exit(*d, lay, packed, ws + w.h2, a, st)) return rc;
     if (concat_out) {   // the workspace holds split-pair rows; hand back plain fp32
         hipLaunchKernelGGL(unsplit_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, lay.F);
@@ -799,6 +809,7 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             a.rec_total = rec_at(corr ? p->rec_total_c : p->rec_total_p, i);
             a.rec_a = corr ? nullptr : rec_at(p->rec_x_mean, i);
             a.rec_b = corr ? nullptr : rec_at(p->rec_x_pred, i);
+            a.parts = ws + w.h2; a.nparts = lay.Hd / SplitGeom::BN; a.part_stride = w.rows_pad * (size_t)lay.V;
             if (int rc = launch_exit(cd, lay, p->cate_packed, ws + w.h2, a, st)) return rc;
             if (corr) {
                 CorrArgs c;
