@@ -81,16 +81,53 @@ struct SplitGeom {
 #define SPLIT_DBG 0      // timing ablations of tests/micro/gemm16_bench.hip (results become wrong): 1 no global loads,
 #endif                   // 2 no LDS stores, 4 no MFMAs, 8 hi*hi MFMAs only, 16 no barriers in the loop
 
+// IN_F32 (training step, dnag_train.hip.h): operands are plain fp32 rows (pitches lda / ldw) and are split while
+// they are staged into LDS (four VALU operations per element, hidden behind the MFMAs), with power-of-two scales
+// that are either the fixed ones or derived on the device from the operand's largest magnitude (gradients are
+// tiny: `amax_a` / `amax_w` point at max|x| as float bits, written by amax_kernel); C is plain fp32 with pitch ldc,
+// epilogues ACT_NONE / ACT_ELU / ACT_MUL_ELUGRAD (aux), and gridDim.y > 1 splits K (slice y stores its partial
+// product at C + y M ldc, to be summed in slice order).
+struct SplitF32Args {
+    int lda, ldw, ldc;
+    const float *amax_a, *amax_w;     // device, or null: SPLIT_SA / SPLIT_SW
+    const float *aux;                 // ACT_MUL_ELUGRAD: aux = elu(z), multiply by elu'(z)
+    float *amax_out;                  // optional: max |C| (float bits, atomicMax) for a later GEMM's operand scale
+};
+
+// power of two s with s * amax in [512, 1024) (1 for amax = 0; capped so that products of two scales stay finite)
+__device__ __forceinline__ float pow2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.0f;
+    int e;
+    frexpf(amax, &e);
+    int k = 10 - e;
+    k = k > 40 ? 40 : (k < -40 ? -40 : k);
+    return ldexpf(1.0f, k);
+}
+
+// *out = max(*out, max |x[i]|) as float bits (non-negative floats order like unsigned integers); *out starts at 0
+__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, size_t n, float *__restrict__ out) {
+    __shared__ float sh[256];
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(sh[0]));
+}
+
 // FUSE_V > 0 (final.linears.1 of the score network): the MFMA operands swap roles, so that a lane holds ONE row of
 // the batch and its registers 16 output columns, and the epilogue applies final.linears.2 (W3 [FUSE_V][Nout],
 // cate.py:55-73) to the ELU output in registers: parts[tn][row][v] = sum over this block's 256 columns of
 // elu(...)[row][col] W3[v][col], summed in a fixed order (lane, lane half, the 4 waves along N).  The 1536-wide
 // hidden activation never reaches HBM; the exit kernel adds the Nout / 256 partial sums and the bias.  C is unused.
-template <int ACT, bool OUT_SPLIT, int TAG, int FUSE_V = 0>
+template <int ACT, bool OUT_SPLIT, int TAG, int FUSE_V = 0, bool IN_F32 = false>
 __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                             const float *__restrict__ bias, float *__restrict__ C,
-                                                            int M, int Nout, int K, const float *__restrict__ W3 = nullptr,
-                                                            float *__restrict__ parts = nullptr) {
+                                                            int M, int Nout, int K, const float *__restrict__ W3,
+                                                            float *__restrict__ parts, const SplitF32Args fa) {
     typedef SplitGeom Ge;
     constexpr int BM = Ge::BM, BN = Ge::BN, RPP = Ge::RPP, NPA = Ge::NPA, NPB = Ge::NPB;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -108,8 +145,16 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
     const int tm = wg / nbn, tn = wg - tm * nbn;
 
     const int lrow = tid >> 3, lk = (tid & 7) * 4;
-    const float *Ag = A + (size_t)(tm * BM + lrow) * K + lk;
-    const float *Wg = W + (size_t)(tn * BN + lrow) * K + lk;
+    const int KT = K / GEMM_BK / (IN_F32 ? (int)gridDim.y : 1);         // k tiles of this slice
+    const int kbase = IN_F32 ? (int)blockIdx.y * KT * GEMM_BK : 0;
+    const int lda = IN_F32 ? fa.lda : K, ldw = IN_F32 ? fa.ldw : K;
+    const float *Ag = A + (size_t)(tm * BM + lrow) * lda + lk + kbase;
+    const float *Wg = W + (size_t)(tn * BN + lrow) * ldw + lk + kbase;
+    float sa = SPLIT_SA, sw = SPLIT_SW;
+    if constexpr (IN_F32) {
+        if (fa.amax_a) sa = pow2_scale(*fa.amax_a);
+        if (fa.amax_w) sw = pow2_scale(*fa.amax_w);
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -120,18 +165,37 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     v4f ra[NPA], rb[NPB];
-    const int KT = K / GEMM_BK;
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int p = 0; p < NPA; ++p) ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(RPP * p) * K + kt * GEMM_BK);
+        for (int p = 0; p < NPA; ++p) ra[p] = *reinterpret_cast<const v4f *>(Ag + (size_t)(RPP * p) * lda + kt * GEMM_BK);
 #pragma unroll
-        for (int p = 0; p < NPB; ++p) rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(RPP * p) * K + kt * GEMM_BK);
+        for (int p = 0; p < NPB; ++p) rb[p] = *reinterpret_cast<const v4f *>(Wg + (size_t)(RPP * p) * ldw + kt * GEMM_BK);
+    };
+    // IN_F32: four fp32 values -> 4 hi halves at their place in the group of 8, 4 lo halves 8 halves further on
+    auto put_split = [&](float *rowp, v4f x, float scale) {
+        h4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = x[e] * scale;
+            hi[e] = (_Float16)v;
+            lo[e] = (_Float16)(v - (float)hi[e]);
+        }
+        _Float16 *d = reinterpret_cast<_Float16 *>(rowp) + (lk >> 3) * 16 + (lk & 7);
+        *reinterpret_cast<h4 *>(d) = hi;
+        *reinterpret_cast<h4 *>(d + 8) = lo;
     };
     auto lstore = [&](int buf) {
+        if constexpr (IN_F32) {
 #pragma unroll
-        for (int p = 0; p < NPA; ++p) *reinterpret_cast<v4f *>(As0 + (buf * BM + lrow + RPP * p) * GEMM_LS + lk) = ra[p];
+            for (int p = 0; p < NPA; ++p) put_split(As0 + (buf * BM + lrow + RPP * p) * GEMM_LS, ra[p], sa);
 #pragma unroll
-        for (int p = 0; p < NPB; ++p) *reinterpret_cast<v4f *>(Bs0 + (buf * BN + lrow + RPP * p) * GEMM_LS + lk) = rb[p];
+            for (int p = 0; p < NPB; ++p) put_split(Bs0 + (buf * BN + lrow + RPP * p) * GEMM_LS, rb[p], sw);
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPA; ++p) *reinterpret_cast<v4f *>(As0 + (buf * BM + lrow + RPP * p) * GEMM_LS + lk) = ra[p];
+#pragma unroll
+            for (int p = 0; p < NPB; ++p) *reinterpret_cast<v4f *>(Bs0 + (buf * BN + lrow + RPP * p) * GEMM_LS + lk) = rb[p];
+        }
     };
     gload(0);
     lstore(0);
@@ -253,6 +317,35 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
         float *dst = parts + ((size_t)tn * M + (size_t)tm * BM) * V;
         for (int i = tid; i < BM * V; i += 512)
             dst[i] = (red[i] + red[BM * V + i]) + (red[2 * BM * V + i] + red[3 * BM * V + i]);
+        return;
+    }
+    if constexpr (IN_F32) {
+        const float inv = 1.0f / (sa * sw);
+        float *Cs = C + (size_t)blockIdx.y * (size_t)M * fa.ldc;
+        float vmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = tn * BN + wn * 64 + j * 32 + r;
+            const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row0 = tm * BM + wm * 128 + i * 32;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const size_t at = (size_t)(row0 + acc_row(e, h)) * fa.ldc + col;
+                    float v = fmaf(acc[i][j][e], inv, bv);
+                    if (ACT == ACT_ELU) v = v > 0.f ? v : __expf(v) - 1.0f;
+                    if (ACT == ACT_MUL_ELUGRAD) { const float a = fa.aux[at]; v *= a > 0.f ? 1.0f : a + 1.0f; }
+                    Cs[at] = v;
+                    vmax = fmaxf(vmax, fabsf(v));
+                }
+            }
+        }
+        if (fa.amax_out) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if (lane == 0) atomicMax(reinterpret_cast<unsigned int *>(fa.amax_out), __float_as_uint(vmax));
+        }
         return;
     }
     // epilogue: scale back, bias, activation; fp32 rows or split-pair rows

@@ -477,15 +477,41 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
         attr_set = true;
     }
+    SplitF32Args nofa;
+    memset(&nofa, 0, sizeof(nofa));
     if (timed) {
         if (V != 7 && V != 9) return fail(DNAG_E_ARG, "fused head GEMM is built for 7 or 9 output columns, got %d", V);
         // C receives the partial sums [Nout / 256][M][V] of final.linears.2
-        hipLaunchKernelGGL(V == 7 ? k7 : k9, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, (float *)nullptr, (int)M, Nout, K, W3, C);
+        hipLaunchKernelGGL(V == 7 ? k7 : k9, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, (float *)nullptr, (int)M, Nout, K, W3, C, nofa);
     } else {
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr);
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr, nofa);
     }
     LAUNCH_CHECK();
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
+    return 0;
+}
+
+// C [M][Nout] (pitch ldc) = act(A W^T + bias) on the split-arithmetic GEMM with fp32 operands split on the fly
+// (dnag_gemm16.hip.h, IN_F32).  amax_a / amax_w: device max|x| of the operand (null: the fixed activation / weight scale).
+template <int ACT, int TAG>
+static int launch_gemm32(const float *A, int lda, const float *amax_a, const float *W, int ldw, const float *amax_w, const float *bias,
+                         float *C, int ldc, const float *aux, size_t M, int Nout, int K, int splitk, hipStream_t st, float *amax_out = nullptr) {
+    typedef SplitGeom Ge;
+    if (M % Ge::BM || Nout % Ge::BN || K % (GEMM_BK * splitk) || lda % 4 || ldw % 4)
+        return fail(DNAG_E_ARG, "split gemm shape %zu x %d x %d (lda %d ldw %d split %d) not tile aligned", M, Nout, K, lda, ldw, splitk);
+    if (splitk > 1 && (ACT != ACT_NONE || bias)) return fail(DNAG_E_ARG, "split-K gemm takes no bias / activation");
+    auto kern = gemm_split_kernel<ACT, false, TAG, 0, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
+        attr_set = true;
+    }
+    SplitF32Args fa;
+    fa.lda = lda; fa.ldw = ldw; fa.ldc = ldc; fa.amax_a = amax_a; fa.amax_w = amax_w; fa.aux = aux; fa.amax_out = amax_out;
+    const int grid = (int)(M / Ge::BM) * (Nout / Ge::BN);
+    hipLaunchKernelGGL(kern, dim3(grid, splitk), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr,
+                       (float *)nullptr, fa);
+    LAUNCH_CHECK();
     return 0;
 }
 
@@ -843,7 +869,7 @@ struct TrainWs {
     size_t rows, rows_pad;
     int nblk_enc, nz_rows, nz_b;
     size_t packed, temb, save_e, save_pre, dpre, dtau, xt, concat, h1, h2, out, dout, dh2, dh1, dconcat, T1, T2;
-    size_t sv_h, sv_h1, sv_qkv, sv_f, part, gsum, scratch, splitk, lossp, total;
+    size_t sv_h, sv_h1, sv_qkv, sv_f, part, gsum, scratch, splitk, lossp, amax, total;
 };
 #define TRAIN_LOSS_BLOCKS 128
 // graphs per workgroup of the encoder BACKWARD: 8 (64 rows, best MFMA tile reuse) once that fills the chip, else 4
@@ -857,7 +883,7 @@ static TrainWs train_ws(const dnag_cate_dims &c, int batch) {
     const GradLayout gl = grad_layout(c);
     const size_t N = c.max_node, V = c.n_vocab, d = c.d_model, dff = c.d_ff, L = c.n_layers, F = tl.enc.F, Hd = tl.enc.Hd;
     w.rows = (size_t)batch * N;
-    w.rows_pad = up(w.rows, GEMM_BM);
+    w.rows_pad = up(w.rows, SplitGeom::BM);
     w.nblk_enc = (batch + train_g(batch) - 1) / train_g(batch);
     w.nz_rows = (int)((w.rows + 127) / 128 < 64 ? (w.rows + 127) / 128 : 64);
     w.nz_b = (batch + 15) / 16 < 64 ? (batch + 15) / 16 : 64;
@@ -890,6 +916,7 @@ static TrainWs train_ws(const dnag_cate_dims &c, int batch) {
     w.scratch = take(64 * big);
     w.splitk = take(8 * Hd * Hd);
     w.lossp = take(TRAIN_LOSS_BLOCKS);
+    w.amax = take(4);            // max |dH2|, max |dH1| (float bits), for the dynamic operand scales of the split GEMM
     w.total = o;
     return w;
 }
@@ -1036,8 +1063,11 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = launch_train_encoder<8>(drop, (B + 7) / 8, P, e, ws + w.xt, ws + w.temb, p->mask, p->mask_stride ? 1 : 0, ws + w.concat, B, sv, dm, st))
         return rc;
     // ---- 3. head MLP and loss ------------------------------------------------------------------------------------
-    if (int rc = launch_gemm_t<ACT_ELU, 3>(ws + w.concat, P + e.f0_w, P + e.f0_b, ws + w.h1, nullptr, rows_pad, Hd, F, F, Hd, Hd, st)) return rc;
-    if (int rc = launch_gemm_t<ACT_ELU, 3>(ws + w.h1, P + e.f1_w, P + e.f1_b, ws + w.h2, nullptr, rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    // all six big GEMMs of the step run on the split-arithmetic fp16 MFMA kernel with fp32 operands split on the fly
+    HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 4 * sizeof(float), st));
+    float *amax_dh2 = ws + w.amax, *amax_dh1 = ws + w.amax + 1;
+    if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.concat, F, nullptr, P + e.f0_w, F, nullptr, P + e.f0_b, ws + w.h1, Hd, nullptr, rows_pad, Hd, F, 1, st)) return rc;
+    if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.h1, Hd, nullptr, P + e.f1_w, Hd, nullptr, P + e.f1_b, ws + w.h2, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
     {
         ExitArgs a;
         memset(&a, 0, sizeof(a));
@@ -1059,28 +1089,30 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = launch_tn_small<0>(ws + w.dout, V, ws + w.h2, Hd, rows, w.nz_rows, V, Hd, scr, G + sl.f2_w, st)) return rc;     // dW3 = dout^T H2
     if (int rc = launch_colsum(ws + w.dout, V, rows, w.nz_rows, V, scr, G + sl.f2_b, st)) return rc;
     hipLaunchKernelGGL((head_out_bwd_kernel<7>), dim3((unsigned)(rows_pad < 2048 ? rows_pad : 2048)), dim3(256), 0, st, ws + w.h2, ws + w.dout,
-                       P + e.f2_w, Hd, rows, rows_pad, ws + w.dh2);
+                       P + e.f2_w, Hd, rows, rows_pad, ws + w.dh2, amax_dh2);
     LAUNCH_CHECK();
     if (int rc = launch_colsum(ws + w.dh2, Hd, rows, w.nz_rows, Hd, scr, G + sl.f1_b, st)) return rc;
     if (int rc = launch_transpose(ws + w.dh2, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
     if (int rc = launch_transpose(ws + w.h1, rows_pad, Hd, Hd, ws + w.T2, rows_pad, rows_pad, st)) return rc;
     // weight gradients reduce over the rows: few output tiles, long K -> split K so that the grid fills the chip
-    auto wgrad_gemm = [&](const float *At, const float *Bt, int Mo, int No, float *dst) -> int {
+    auto wgrad_gemm = [&](const float *At, const float *amax_at, const float *Bt, int Mo, int No, float *dst) -> int {
+        const int tiles = (Mo / SplitGeom::BM) * (No / SplitGeom::BN);
         int split = 1;
-        while (split < 8 && (Mo / GEMM_BM) * (No / GEMM_BN) * split < 512 && (rows_pad / GEMM_BK) % (2 * split) == 0) split *= 2;
-        if (split == 1) return launch_gemm_t<ACT_NONE, 3>(At, Bt, nullptr, dst, nullptr, Mo, No, (int)rows_pad, (int)rows_pad, No, No, st);
-        if (int rc = launch_gemm_t<ACT_NONE, 4>(At, Bt, nullptr, ws + w.splitk, nullptr, Mo, No, (int)rows_pad, (int)rows_pad, No, No, st, split)) return rc;
+        while (split < 16 && tiles * split < 256 && (rows_pad / GEMM_BK) % (2 * split) == 0) split *= 2;
+        if (int rc = launch_gemm32<ACT_NONE, 4>(At, (int)rows_pad, amax_at, Bt, (int)rows_pad, nullptr, nullptr, ws + w.splitk, No, nullptr, Mo, No,
+                                                (int)rows_pad, split, st))
+            return rc;
         const size_t n = (size_t)Mo * No;
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, ws + w.splitk, split, n, n, dst, 1.0f);
         return hipGetLastError() == hipSuccess ? 0 : fail(DNAG_E_HIP, "reduce_parts_kernel launch failed");
     };
-    if (int rc = wgrad_gemm(ws + w.T1, ws + w.T2, Hd, Hd, G + sl.f1_w)) return rc;   // dW2 = dH2^T H1
-    if (int rc = launch_gemm_t<ACT_MUL_ELUGRAD, 3>(ws + w.dh2, P + tl.f1T, nullptr, ws + w.dh1, ws + w.h1, rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    if (int rc = wgrad_gemm(ws + w.T1, amax_dh2, ws + w.T2, Hd, Hd, G + sl.f1_w)) return rc;   // dW2 = dH2^T H1
+    if (int rc = launch_gemm32<ACT_MUL_ELUGRAD, 3>(ws + w.dh2, Hd, amax_dh2, P + tl.f1T, Hd, nullptr, nullptr, ws + w.dh1, Hd, ws + w.h1, rows_pad, Hd, Hd, 1, st, amax_dh1)) return rc;
     if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, st)) return rc;
     if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
     if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, st)) return rc;
-    if (int rc = wgrad_gemm(ws + w.T1, ws + w.T2, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
-    if (int rc = launch_gemm_t<ACT_NONE, 3>(ws + w.dh1, P + tl.f0T, nullptr, ws + w.dconcat, nullptr, rows_pad, F, Hd, Hd, F, F, st)) return rc;
+    if (int rc = wgrad_gemm(ws + w.T1, amax_dh1, ws + w.T2, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
+    if (int rc = launch_gemm32<ACT_NONE, 3>(ws + w.dh1, Hd, amax_dh1, P + tl.f0T, Hd, nullptr, nullptr, ws + w.dconcat, F, nullptr, rows_pad, F, Hd, 1, st)) return rc;
     // ---- 5. encoder backward -----------------------------------------------------------------------------------------
     if (int rc = train_g(B) == 8 ? launch_train_enc_bwd<8>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st)
                                  : launch_train_enc_bwd<4>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st))

@@ -262,6 +262,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A
 // out[i] = scale * sum_p in[p * stride + i], p ascending (fixed order: reproducible)
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float *__restrict__ in, int nparts, size_t stride, size_t n,
                                                            float *__restrict__ out, float scale) {
+    if (((n | stride) & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+            v4f acc = *reinterpret_cast<const v4f *>(in + i);
+            for (int p = 1; p < nparts; ++p) {
+                const v4f v = *reinterpret_cast<const v4f *>(in + (size_t)p * stride + i);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
+            *reinterpret_cast<v4f *>(out + i) = acc;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         float acc = 0.f;
         for (int p = 0; p < nparts; ++p) acc += in[(size_t)p * stride + i];
@@ -316,7 +328,9 @@ __global__ __launch_bounds__(256) void dsm_loss_kernel(const float *__restrict__
 template <int V>
 __global__ __launch_bounds__(256) void head_out_bwd_kernel(const float *__restrict__ h2, const float *__restrict__ dout,
                                                            const float *__restrict__ W3, int K, size_t rows_live, size_t rows_pad,
-                                                           float *__restrict__ dh2) {
+                                                           float *__restrict__ dh2, float *__restrict__ amax_out) {
+    __shared__ float shmax[256];
+    float vmax = 0.f;
     const int tid = threadIdx.x;
     for (int c = tid; c < K; c += 256) {
         float w[V];
@@ -333,8 +347,17 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const float *__restri
                 g = acc * (a > 0.f ? 1.0f : a + 1.0f);
             }
             dh2[r * K + c] = g;
+            vmax = fmaxf(vmax, fabsf(g));
         }
     }
+    // max |dh2| (float bits) for the operand scale of the split GEMMs that consume dh2
+    shmax[tid] = vmax;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) shmax[tid] = fmaxf(shmax[tid], shmax[tid + s2]);
+        __syncthreads();
+    }
+    if (tid == 0 && amax_out) atomicMax(reinterpret_cast<unsigned int *>(amax_out), __float_as_uint(shmax[0]));
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -20,6 +20,8 @@ case $step in
   prof)   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
           run 300 prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
           tail -1 gpurun_out/prof.log ;;
+  profofa) run 300 prof_ofa.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ofa -o ofa -- python3 bench.py --workload ofa --steps 1 --warmup 0 --sde-steps 100 --no-cpu-baseline
+          tail -1 gpurun_out/prof_ofa.log ;;
   proftrain) run 200 prof_train.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_train -o train -- python3 bench.py --workload train --steps 20
           tail -1 gpurun_out/prof_train.log ;;
   pmc)    # HBM/fabric traffic of the per-evaluation kernels: separate passes, as the guide's HBM section prescribes

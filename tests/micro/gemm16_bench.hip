@@ -42,7 +42,7 @@ int main() {
     const int grid = (M / Ge::BM) * (N / Ge::BN);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(Ge::T), Ge::lds_bytes, 0, A, W, bias, C, M, N, K);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(grid), dim3(Ge::T), Ge::lds_bytes, 0, A, W, bias, C, M, N, K, (const float *)nullptr, (float *)nullptr, SplitF32Args{});
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("gemm_split 256x256 DBG=%d: %.1f us per launch, %.1f TFLOP/s (algorithmic), %.1f TFLOP/s of fp16 MFMA issued\n", SPLIT_DBG,
