@@ -69,6 +69,8 @@ class PcArgsC(C.Structure):
         ("rec_total_p", _fp), ("rec_x_mean", _fp), ("rec_x_pred", _fp),
         ("rec_cgrad_c", _fp), ("rec_cgrad_p", _fp), ("rec_step_size", _fp),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+        ("cscale_steps", _fp), ("guide_steps", C.c_void_p), ("weight_ratio", C.c_int32), ("weight_ratio_p", C.c_float),
+        ("prod_w", C.c_int32),
     ]
 
 

@@ -176,6 +176,11 @@ struct ExitArgs {
     const float *parts;
     int nparts;
     size_t part_stride;
+    // guidance weighting of the MobileNetV3 sampler (MobileNetV3/sampling.py:880-891): 0 none, 1 per-sample norm ratio,
+    // 2 per-element |score| / |grad|
+    int wr_mode;
+    float wr_p;
+    int prod_w;
 };
 
 // H2 [rows_pad][K]; W3 [V][K]; b3 [V].  One block = GF graphs = GF*N <= 64 rows.
@@ -229,6 +234,46 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
     for (int v = 0; v < V; ++v) red[kq][r][v] = acc[v];
     __syncthreads();
 
+    auto model_out = [&](int rr, int v, size_t e) -> float {
+        if (a.parts) {
+            float val = a.parts[e];
+            for (int p = 1; p < a.nparts; ++p) val += a.parts[(size_t)p * a.part_stride + e];
+            return val + b3[v];
+        }
+        return ((red[0][rr][v] + red[1][rr][v]) + (red[2][rr][v] + red[3][rr][v])) + b3[v];
+    };
+    // per-sample weight ratio ||score_b||_p / ||grad_b||_p: scores and gradients of the block's graphs go through LDS,
+    // one thread per graph sums them in element order
+    __shared__ float gratio[GF];
+    if (a.wr_mode == 1 && a.cgrad != nullptr && a.mode != EXIT_FORWARD) {
+        for (int i = tid; i < 64 * V; i += 256) {
+            const int rr = i / V, v = i - rr * V;
+            const bool valid = rr < R && (blockIdx.x * GF + rr / N) < a.batch;
+            float sc = 0.f, cg = 0.f;
+            if (valid) {
+                const size_t e = (size_t)(row0 + rr) * V + v;
+                const float val = model_out(rr, v, e);
+                sc = a.score_mode == DNAG_SCORE_VP ? __fdiv_rn(-val, a.std) : val;
+                cg = a.cgrad[e];
+            }
+            tot[i] = sc;
+            nz[i] = cg;
+        }
+        __syncthreads();
+        if (tid < GF) {
+            float sp = 0.f, cp = 0.f;
+            for (int i = 0; i < N * V; ++i) {
+                const float s1 = fabsf(tot[tid * N * V + i]), c1 = fabsf(nz[tid * N * V + i]) * (a.prod_w ? fabsf(a.cscale) : 1.0f);
+                if (a.wr_p == 1.0f) { sp += s1; cp += c1; }
+                else if (a.wr_p == 2.0f) { sp = fmaf(s1, s1, sp); cp = fmaf(c1, c1, cp); }
+                else { sp += powf(s1, a.wr_p); cp += powf(c1, a.wr_p); }
+            }
+            if (a.wr_p == 2.0f) { sp = sqrtf(sp); cp = sqrtf(cp); }
+            else if (a.wr_p != 1.0f) { sp = powf(sp, 1.0f / a.wr_p); cp = powf(cp, 1.0f / a.wr_p); }
+            gratio[tid] = __fdiv_rn(sp, cp);
+        }
+        __syncthreads();
+    }
     // one thread per (row, v) element of this block
     for (int i = tid; i < 64 * V; i += 256) {
         const int rr = i / V, v = i - rr * V;
@@ -237,21 +282,20 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
         float total = 0.f, noise = 0.f;
         if (valid) {
             const size_t e = (size_t)(row0 + rr) * V + v;
-            float val;
-            if (a.parts) {
-                val = a.parts[e];
-                for (int p = 1; p < a.nparts; ++p) val += a.parts[(size_t)p * a.part_stride + e];
-                val += b3[v];
-            } else {
-                val = ((red[0][rr][v] + red[1][rr][v]) + (red[2][rr][v] + red[3][rr][v])) + b3[v];
-            }
+            const float val = model_out(rr, v, e);
             if (a.mode == EXIT_FORWARD) {
                 if (a.out_gstride) a.out[(size_t)(blockIdx.x * GF + g) * a.out_gstride + (rr - g * N) * V + v] = val;
                 else a.out[e] = val;
             } else {
                 const float score = a.score_mode == DNAG_SCORE_VP ? __fdiv_rn(-val, a.std) : val;   // models/utils.py:103 | :116
                 total = score;
-                if (a.cgrad != nullptr) total = __fadd_rn(score, __fmul_rn(a.cscale, a.cgrad[e]));  // sampling.py:505
+                if (a.cgrad != nullptr) {
+                    const float cg = a.cgrad[e];
+                    float w = a.cscale;
+                    if (a.wr_mode == 1) w = __fmul_rn(w, gratio[g]);                                        // MBV3 sampling.py:886
+                    else if (a.wr_mode == 2) w = __fmul_rn(w, __fdiv_rn(fabsf(score), fabsf(cg)));        // :890-891
+                    total = __fadd_rn(score, __fmul_rn(w, cg));                                            // sampling.py:505
+                }
                 if (a.rec_score) a.rec_score[e] = score;
                 if (a.rec_total) a.rec_total[e] = total;
                 noise = a.noise ? a.noise[e] : philox_normal(a.seed, a.stream_offset + e, a.draw);

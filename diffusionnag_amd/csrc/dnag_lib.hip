@@ -762,6 +762,8 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
         return fail(DNAG_E_ARG, "predictor=%d is not a DNAG_PREDICTOR_* value", p->predictor);
     if (p->score_mode != DNAG_SCORE_VP && p->score_mode != DNAG_SCORE_VE) return fail(DNAG_E_ARG, "score_mode=%d", p->score_mode);
     if (!p->x0 && !(p->prior_scale > 0.f)) return fail(DNAG_E_ARG, "prior_scale=%g must be positive when x0 is NULL", p->prior_scale);
+    if (p->weight_ratio < 0 || p->weight_ratio > 2 || (p->weight_ratio == 1 && !(p->weight_ratio_p > 0.f)))
+        return fail(DNAG_E_ARG, "weight_ratio=%d weight_ratio_p=%g", p->weight_ratio, p->weight_ratio_p);
     if ((p->noise_corr == nullptr) != (p->noise_pred == nullptr) && p->corrector)
         return fail(DNAG_E_ARG, "noise_corr and noise_pred must both be given (tape mode) or both NULL (Philox)");
     const dnag_cate_dims &cd = *p->cate_dims;
@@ -809,7 +811,8 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
         // phase 0: corrector, phase 1: predictor; a None corrector / predictor evaluates nothing (sampling.py:216-224, :259-267)
         for (int phase = p->corrector ? 0 : 1; phase < (p->predictor == DNAG_PREDICTOR_NONE ? 1 : 2); ++phase) {
             const bool corr = phase == 0;
-            if (guided) {
+            const bool guide_now = guided && (p->guide_steps == nullptr || p->guide_steps[i] != 0);
+            if (guide_now) {
                 if (guided_pc) {
                     if (int rc = run_predcate(pclay, p->predcate_packed, x, ws + w.temb_p + (size_t)i * pclay.enc.d, 0, p->mask, 0, nullptr, cgrad, B, ws + w.pc, pcw, st)) return rc;
                 } else if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, p->d_mu, nullptr, cgrad, B, st)) return rc;
@@ -823,8 +826,9 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             a.batch = B;
             a.std = row[DNAG_SCHED_STD];
             a.score_mode = p->score_mode; a.pred_kind = p->predictor; a.dt = row[DNAG_SCHED_DT];
-            a.cgrad = guided ? cgrad : nullptr;
-            a.cscale = p->classifier_scale * p->label_sign;
+            a.cgrad = guide_now ? cgrad : nullptr;
+            a.cscale = (p->cscale_steps ? p->cscale_steps[i] : p->classifier_scale) * p->label_sign;
+            a.wr_mode = p->weight_ratio; a.wr_p = p->weight_ratio_p; a.prod_w = p->prod_w;
             a.gbuf = gbuf; a.partials = partials;
             a.x = x; a.x_mean = x_mean;
             a.sqrt_alpha = row[DNAG_SCHED_SQRTA]; a.G = row[DNAG_SCHED_G]; a.G2 = row[DNAG_SCHED_G2];

@@ -99,8 +99,12 @@ class NoneCorrector:
     enabled = 0
 
 
-def get_sampling_fn(config, sde, shape, inverse_scaler, eps, conditional=False, data_name='cifar10', num_sample=20):
-    """Create a sampling function (reference ``sampling.py:64-133``, same arguments)."""
+def get_sampling_fn(config, sde, shape, inverse_scaler, eps, conditional=False, data_name='cifar10', num_sample=20,
+                    p=1, prod_w=False, weight_ratio_abs=False):
+    """Create a sampling function (reference ``sampling.py:64-133``, same arguments).  ``p``, ``prod_w``,
+    ``weight_ratio_abs`` and ``config.sampling.{weight_scheduling, weight_ratio, t_spot, t_spot_end}`` are the guidance
+    weighting options of the MobileNetV3 tree's factory (``MobileNetV3/sampling.py:72-190``); absent = the
+    NAS-Bench-201 tree's behaviour."""
     sampler_name = config.sampling.method
     if sampler_name.lower() == 'pc':
         predictor = get_predictor(config.sampling.predictor.lower())
@@ -112,8 +116,14 @@ def get_sampling_fn(config, sde, shape, inverse_scaler, eps, conditional=False, 
                       denoise=config.sampling.noise_removal, eps=eps, device=config.device, noise=noise)
         if not conditional:
             return get_pc_sampler_nas(**common)
+        sc = config.sampling
+        weighting = dict(weight_scheduling=bool(sc.weight_scheduling) if 'weight_scheduling' in sc else False,
+                         weight_ratio=bool(sc.weight_ratio) if 'weight_ratio' in sc else False,
+                         t_spot=float(sc.t_spot) if 't_spot' in sc else 1.,
+                         t_spot_end=sc.t_spot_end if 't_spot_end' in sc else None,
+                         p=p, prod_w=bool(prod_w), weight_ratio_abs=bool(weight_ratio_abs))
         return get_pc_conditional_sampler_meta_nas(regress=config.sampling.regress, labels=config.sampling.labels,
-                                                   data_name=data_name, num_sample=num_sample, **common)
+                                                   data_name=data_name, num_sample=num_sample, weighting=weighting, **common)
     raise NotImplementedError(f"Sampler name {sampler_name} unknown.")
 
 
@@ -149,8 +159,35 @@ class _PCSampler:
         self.last_record: Optional[dict] = None
         self.seed = 0
         self.stream_offset = 0
+        self.weighting: Optional[dict] = None
         self._ws = Workspace()
         self._calls = 0
+
+    def _guidance_schedule(self, S, classifier_scale):
+        """Per-step guidance weight and on/off flag of the MobileNetV3 sampler's ``total_grad_fn``
+        (``MobileNetV3/sampling.py:858-859``, ``:875-878``, ``:902-910``), computed like the reference: python floats
+        (double) from the fp32 time grid.  Returns ``(cscale_steps, guide_steps, mode, p, prod_w)`` or None."""
+        wo = self.weighting
+        if not wo:
+            return None
+        mode = 1 if wo.get("weight_ratio") else (2 if wo.get("weight_ratio_abs") else 0)
+        if wo.get("weight_ratio") and wo.get("weight_ratio_abs"):
+            raise AssertionError("weight_ratio and weight_ratio_abs are exclusive (MobileNetV3/sampling.py:889)")
+        t_spot = wo.get("t_spot", 1.)
+        if not (wo.get("weight_scheduling") or mode or t_spot < 1.):
+            return None
+        t_end = wo.get("t_spot_end")
+        if t_end is None or t_end == 0.:
+            t_end = self.eps
+        ts = torch.linspace(self.sde.T, self.eps, self.sde.N)[:S]
+        cs = np.empty(S, np.float32)
+        on = np.ones(S, np.int32)
+        for i in range(S):
+            t0 = ts[i].item()
+            cs[i] = classifier_scale * 0.1 ** t0 if wo.get("weight_scheduling") else classifier_scale
+            if t_spot < 1. and not (t0 <= t_spot and bool(ts[i] >= t_end)):
+                on[i] = 0
+        return cs, on, mode, float(wo.get("p", 1)), int(bool(wo.get("prod_w")))
 
     # ---------------------------------------------------------------------------------------------
     def _run(self, score_model: CATE, mask, classifier=None, classifier_scale=None, task=None, labels='max'):
@@ -196,6 +233,12 @@ class _PCSampler:
             args.classifier_scale = float(classifier_scale)
             args.label_sign = 1.0 if labels == 'max' else -1.0
             keep += [d_mu]
+            gs = self._guidance_schedule(S, float(classifier_scale))
+            if gs is not None:
+                cs, on, mode, pnorm, prod_w = gs
+                args.cscale_steps, args.guide_steps = cs.ctypes.data, on.ctypes.data
+                args.weight_ratio, args.weight_ratio_p, args.prod_w = mode, pnorm, prod_w
+                keep += [cs, on]
         args.batch, args.n_steps = B, S
         args.mask = _lib.ptr(m)
         args.sched = sched.ctypes.data
@@ -279,8 +322,9 @@ class _PCUnconditional(_PCSampler):
 
 
 class _PCConditional(_PCSampler):
-    def __init__(self, *a, regress=True, labels='max', data_name='cifar10', num_sample=20, **k):
+    def __init__(self, *a, regress=True, labels='max', data_name='cifar10', num_sample=20, weighting=None, **k):
         super().__init__(*a, **k)
+        self.weighting = weighting
         if not regress:
             raise NotImplementedError("classification guidance (regress=False) is not built")
         assert labels in ['max', 'min']
@@ -305,8 +349,8 @@ def get_pc_sampler_nas(sde, shape, predictor, corrector, inverse_scaler, snr, n_
 def get_pc_conditional_sampler_meta_nas(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1,
                                         probability_flow=False, continuous=False, denoise=True, eps=1e-5,
                                         device='cuda', regress=True, labels='max', data_name='cifar10',
-                                        num_sample=20, noise='philox'):
-    """Reference ``sampling.py:450-579``."""
+                                        num_sample=20, noise='philox', weighting=None):
+    """Reference ``sampling.py:450-579``; ``weighting``: the extra options of ``MobileNetV3/sampling.py:816-823``."""
     return _PCConditional(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow,
                           continuous, denoise, eps, device, noise, regress=regress, labels=labels,
-                          data_name=data_name, num_sample=num_sample)
+                          data_name=data_name, num_sample=num_sample, weighting=weighting)

@@ -120,3 +120,72 @@ def quantize(x):
         _lib.check(lib.dnag_quantize(xc.data_ptr(), q.data_ptr(), xc.numel(), _lib.current_stream(dev)), "dnag_quantize")
     host = q.cpu().numpy()
     return [host[i] for i in range(host.shape[0])]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Checkpoints (reference ``utils.py:84-121``; layout in SURVEY.md Appendix C)
+# ---------------------------------------------------------------------------------------------------
+def _safe_load(path, device):
+    """``torch.load`` that executes nothing from the file.  The reference stores its ``ml_collections.ConfigDict``
+    in the checkpoint; ``weights_only=True`` refuses such a class unless the caller has allow-listed it with
+    ``torch.serialization.add_safe_globals`` -- the error says so instead of falling back to an unsafe load."""
+    try:
+        return torch.load(path, map_location=device, weights_only=True)
+    except Exception as e:   # noqa: BLE001 - re-raised with advice
+        raise RuntimeError(
+            f"{path}: refused by the safe loader ({type(e).__name__}: {e}).  Checkpoints written by the reference hold a "
+            "ConfigDict under 'config': allow-list its classes with torch.serialization.add_safe_globals([...]) or re-save "
+            "the checkpoint with only 'model', 'ema', 'optimizer' and 'step'.") from e
+
+
+def restore_checkpoint(ckpt_dir, state, device, resume=False):
+    """Reference ``utils.py:84-101``: same arguments and behaviour, safe loader."""
+    import logging
+    import os
+    if not resume:
+        os.makedirs(os.path.dirname(ckpt_dir), exist_ok=True)
+        return state
+    if not os.path.exists(ckpt_dir):
+        os.makedirs(os.path.dirname(ckpt_dir), exist_ok=True)
+        logging.warning(f"No checkpoint found at {ckpt_dir}. Returned the same state as input")
+        return state
+    loaded_state = _safe_load(ckpt_dir, device)
+    for k in state:
+        if k in ['optimizer', 'model', 'ema']:
+            state[k].load_state_dict(loaded_state[k])
+        else:
+            state[k] = loaded_state[k]
+    return state
+
+
+def save_checkpoint(ckpt_dir, state, step, save_step, is_best, remove_except_best=False):
+    """Reference ``utils.py:104-121``: ``checkpoint_{step}_{save_step}.pth.tar`` (+ ``model_best.pth.tar``)."""
+    import os
+    import shutil
+    saved_state = {k: (state[k].state_dict() if k in ['optimizer', 'model', 'ema'] else state[k]) for k in state}
+    os.makedirs(ckpt_dir, exist_ok=True)
+    path = os.path.join(ckpt_dir, f'checkpoint_{step}_{save_step}.pth.tar')
+    torch.save(saved_state, path)
+    if is_best:
+        shutil.copy(path, os.path.join(ckpt_dir, 'model_best.pth.tar'))
+    if remove_except_best:
+        for f in sorted(os.listdir(ckpt_dir)):
+            if f.startswith('checkpoint') and os.path.join(ckpt_dir, f) != os.path.join(ckpt_dir, 'model_best.pth.tar'):
+                os.remove(os.path.join(ckpt_dir, f))
+
+
+def load_score_model(ckpt_path, config, device=None):
+    """Reference ``run_lib.get_score_model`` (``main_exp/diffusion/run_lib.py:61-79``): create the model, load
+    ``'model'``, then copy the EMA shadow parameters into it (``ema.copy_to``), which is what every sampling caller
+    does before using the network."""
+    from . import mutils
+    from .ema import ExponentialMovingAverage
+    model = mutils.create_model(config)
+    loaded = _safe_load(ckpt_path, device or config.device)
+    model.load_state_dict(loaded['model'], strict=False)
+    ema = ExponentialMovingAverage(model.parameters(), decay=loaded['ema']['decay'] if 'ema' in loaded else 0.9999)
+    if 'ema' in loaded:
+        ema.load_state_dict(loaded['ema'])
+        ema.shadow_params = [p.to(next(model.parameters()).device) for p in ema.shadow_params]
+        ema.copy_to(model.parameters())
+    return model, ema

@@ -196,6 +196,20 @@ typedef struct dnag_pc_args {
     void *workspace;
     size_t workspace_bytes;
     void *stream;
+    /* guidance weighting options of the MobileNetV3 tree's sampler (MobileNetV3/sampling.py:858-910, :924-957); all
+     * zero / NULL = the NAS-Bench-201 tree's total_grad_fn (sampling.py:502-505).
+     *   cscale_steps  HOST [n_steps] or NULL: the weight of step i instead of classifier_scale
+     *                 (weight_scheduling: scale * 0.1 ** t_i, computed by the host mirror like the reference, in double)
+     *   guide_steps   HOST [n_steps] or NULL: 0 = this step uses the plain score (t outside [t_spot_end, t_spot]);
+     *                 the surrogate is not evaluated at all on such a step
+     *   weight_ratio  0 none | 1 per sample: w *= ||score_b||_p / ||grad_b||_p (prod_w: / ||w grad_b||_p)
+     *                 | 2 per element: w *= |score| / |grad| (weight_ratio_abs)
+     *   weight_ratio_p  the norm's p (1 in the reference's callers) */
+    const float *cscale_steps;
+    const int32_t *guide_steps;
+    int32_t weight_ratio;
+    float weight_ratio_p;
+    int32_t prod_w;
 } dnag_pc_args;
 
 int dnag_pc_sample(const dnag_pc_args *args);

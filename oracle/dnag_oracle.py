@@ -427,8 +427,17 @@ def classifier_grad_cate(sd: SD, x: Tensor, t: Tensor, maskX: Tensor, D_mu: Tens
 def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3, snr: float = 0.16,
               n_steps: Optional[int] = None, pred_sd: Optional[SD] = None, D_mu: Optional[Tensor] = None,
               classifier_scale: float = 0.0, labels: str = "max", record: Optional[list] = None,
-              model_kw: Optional[dict] = None, predictor: str = "reverse_diffusion", corrector: str = "langevin") -> Tensor:
+              model_kw: Optional[dict] = None, predictor: str = "reverse_diffusion", corrector: str = "langevin",
+              weighting: Optional[dict] = None) -> Tensor:
     """Predictor-corrector loop with injected noise (sampling.py:424-445 / :534-577).
+
+    ``weighting`` (None: the NAS-Bench-201 tree's ``score + classifier_scale * grad``) restates the guidance weighting
+    options that only the MobileNetV3 tree's sampler has (MobileNetV3/sampling.py:858-910, :924-957): keys
+    ``weight_scheduling`` (w = scale * 0.1 ** t), ``weight_ratio`` (w *= ||score_b||_p / ||grad_b||_p per sample;
+    ``prod_w``: / ||w grad_b||_p), ``weight_ratio_abs`` (w *= |score| / |grad| per element), ``p``, ``t_spot`` /
+    ``t_spot_end`` (guidance only while t_spot_end <= t <= t_spot).  PARITY UNPINNED for these options: that file
+    imports torchdiffeq, which is not installed here, so the reference cannot be run for them; the restatement
+    follows its text and is checked against the kernels only.
 
     ``predictor``: 'reverse_diffusion' (sampling.py:203-213), 'euler_maruyama' (:189-200) or 'none'
     (:216-224); ``corrector``: 'langevin' (:227-256) or 'none' (:259-267); ``sde``: VPSDE or VESDE.
@@ -450,7 +459,24 @@ def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3,
             return s, s, None
         grad_fn = classifier_grad_cate if "regeress.linears.0.weight" in pred_sd else classifier_grad
         cg = grad_fn(pred_sd, x, vec_t, maskX, D_mu, labels, sde)
-        return s + classifier_scale * cg, s, cg
+        if weighting is None:
+            return s + classifier_scale * cg, s, cg
+        wo = weighting
+        p = wo.get("p", 1)
+        t0 = vec_t[0].item()
+        w = classifier_scale * 0.1 ** t0 if wo.get("weight_scheduling") else classifier_scale      # MBV3 :858-859, :875-878
+        if wo.get("weight_ratio"):                                                                   # :880-886
+            den = (w * cg) if wo.get("prod_w") else cg
+            ratio = s.view(B, -1).norm(p=p, dim=-1) / den.view(B, -1).norm(p=p, dim=-1)
+            w = w * ratio[:, None, None]
+        if wo.get("weight_ratio_abs"):                                                               # :888-891
+            assert not wo.get("weight_ratio")
+            w = w * torch.div(torch.abs(s), torch.abs(cg))
+        t_spot = wo.get("t_spot", 1.)
+        t_end = wo.get("t_spot_end") or eps                                                          # :855-856
+        if t_spot < 1. and not (t0 <= t_spot and vec_t[0] >= t_end):                                 # :902-907
+            return s, s, cg
+        return s + w * cg, s, cg
 
     x_mean = x
     with torch.no_grad():

@@ -424,3 +424,41 @@ def test_ema_mirror_matches_reference_formula():
     ema.restore(ps)
     assert not torch.equal(ps[0].data, ema.shadow_params[0])
     assert set(ema.state_dict()) == {"decay", "num_updates", "shadow_params"}
+
+
+def test_checkpoint_round_trip_and_safe_loader(tmp_path):
+    """save_checkpoint / restore_checkpoint / load_score_model mirrors (reference utils.py:84-121,
+    main_exp/diffusion/run_lib.py:61-79) on a checkpoint written here; a file holding an arbitrary object is refused."""
+    from diffusionnag_amd.ema import ExponentialMovingAverage
+    cfg = score_config(CateDims(), "cpu")
+    model = mutils.create_model(cfg)
+    model.load_state_dict(synthetic.cate_state_dict(CateDims(), seed=0))
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01)
+    ema.update(model.parameters())
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    state = dict(optimizer=opt, model=model, ema=ema, step=7)
+    ckdir = str(tmp_path / "ck")
+    utils.save_checkpoint(ckdir, state, 7, 1, is_best=True)
+    path = os.path.join(ckdir, "model_best.pth.tar")
+    assert os.path.exists(path) and os.path.exists(os.path.join(ckdir, "checkpoint_7_1.pth.tar"))
+    model2 = mutils.create_model(cfg)
+    ema2 = ExponentialMovingAverage(model2.parameters(), decay=0.5)
+    state2 = utils.restore_checkpoint(path, dict(optimizer=torch.optim.Adam(model2.parameters(), lr=1e-3), model=model2, ema=ema2, step=0),
+                                      "cpu", resume=True)
+    assert state2["step"] == 7 and ema2.decay == 0.999 and ema2.num_updates == 1
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), model2.state_dict().values()))
+    m3, e3 = utils.load_score_model(path, cfg)
+    assert all(torch.equal(p, s) for p, s in zip(m3.parameters(), ema.shadow_params))      # the EMA weights are what samples
+    bad = str(tmp_path / "bad.pth.tar")
+    torch.save({"model": model.state_dict(), "config": Cfg_like()}, bad)
+    with pytest.raises(RuntimeError, match="safe loader"):
+        utils.restore_checkpoint(bad, dict(model=model2), "cpu", resume=True)
+
+
+class Cfg_like:
+    """Stands for the reference's ConfigDict inside a checkpoint: an arbitrary class the safe loader must refuse."""
+    def __init__(self):
+        self.x = 1
