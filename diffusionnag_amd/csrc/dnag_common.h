@@ -30,6 +30,8 @@ struct CateLayout {
     size_t f0_w, f0_b, f1_w, f1_b, f2_w, f2_b;  // final.linears.{0,1,2}
     size_t pe, freq;              // [N][d], [d/2]
     size_t f0_s, f1_s;            // final.linears.{0,1} weights as split-pair fp16 rows (dnag_gemm16.hip.h), same sizes
+    size_t delta16;               // layer0 + delta16: second copy of the layer blocks whose four matrices are fp16 hi/lo
+                                  // fragments scaled by 256 (frag16_pack) for the encoder's split-arithmetic MFMAs
     size_t total;
     int F, Hd;                    // F = L*d (concat width), Hd = 2F (head hidden)
 };
@@ -71,6 +73,7 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
     y.freq = o; o += align4(d / 2);
     y.f0_s = o; o += Hd * F;
     y.f1_s = o; o += Hd * Hd;
+    y.delta16 = o - y.layer0; o += y.layer_stride * y.L;
     y.total = o;
     return y;
 }
@@ -92,6 +95,23 @@ static inline void frag_pack(const float *W, size_t rows, size_t K, size_t ld, f
                 for (size_t e = 0; e < 4; ++e) {
                     const size_t row = nt * 32 + (l & 31), k = (l >> 5) * KH + 4 * q + e;
                     out[((nt * NQ + q) * 64 + l) * 4 + e] = row < rows ? W[row * ld + k] : 0.f;
+                }
+}
+
+// Split-arithmetic variant of frag_pack (dnag_gemm16.hip.h explains the arithmetic): the same fragment-major
+// addressing and byte size, but the 16-byte chunk q of a lane holds 8 fp16 values: chunks 2s and 2s+1 are the hi and
+// the lo halves of 256 * W[nt*32 + r][h*K/2 + 8s .. 8s+7], i.e. the B fragments of 32x32x16 step s.
+static inline void frag16_pack(const float *W, size_t rows, size_t K, size_t ld, float *out) {
+    const size_t ntiles = (rows + 31) / 32, KH = K / 2, NQ = K / 8;
+    _Float16 *o = reinterpret_cast<_Float16 *>(out);
+    for (size_t nt = 0; nt < ntiles; ++nt)
+        for (size_t q = 0; q < NQ; ++q)
+            for (size_t l = 0; l < 64; ++l)
+                for (size_t j = 0; j < 8; ++j) {
+                    const size_t row = nt * 32 + (l & 31), k = (l >> 5) * KH + 8 * (q >> 1) + j;
+                    const float w = row < rows ? W[row * ld + k] * 256.0f : 0.f;
+                    const _Float16 hi = (_Float16)w;
+                    o[((nt * NQ + q) * 64 + l) * 8 + j] = (q & 1) ? (_Float16)(w - (float)hi) : hi;
                 }
 }
 
@@ -222,6 +242,10 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+// D[32x32] += A[32x16] * B[16x32] on fp16: lane (r, h) supplies A[r][8h .. 8h+7] and B[8h .. 8h+7][r]; same C/D layout
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

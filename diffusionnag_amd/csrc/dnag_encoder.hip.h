@@ -112,7 +112,10 @@ struct JobSplit {
     __device__ static __forceinline__ int first_tile(int wave) { return wave * per < njobs ? (wave * per) / MT : -1; }
 };
 
-template <int K, int NTILES, int MT, int NW, bool LN, typename BLoad, typename Epi>
+// F16: split-arithmetic MFMAs (dnag_gemm16.hip.h): the B registers hold frag16_pack fragments (fp16 hi/lo of 256 W),
+// every A value is scaled by 16 and split after the LayerNorm, three v_mfma_f32_32x32x16_f16 per 8 k values replace
+// eight v_mfma_f32_32x32x2_f32, and the accumulator is scaled back by 2^-12 before the epilogue.
+template <int K, int NTILES, int MT, int NW, bool LN, bool F16 = false, typename BLoad, typename Epi>
 __device__ __forceinline__ void run_jobs2(const float *A, int as, float (&b0)[K / 2], float (&b1)[K / 2], BLoad bload, Epi epi) {
     typedef JobSplit<NTILES, MT, NW> JS;
     static_assert(JS::max_tiles() <= 2, "a wave's job chunk may span at most two column tiles");
@@ -154,13 +157,37 @@ __device__ __forceinline__ void run_jobs2(const float *A, int as, float (&b0)[K 
 #pragma unroll
                 for (int i = 0; i < CH; ++i) a[i] *= rs;
             }
-            if (first) {
+            if constexpr (F16) {
+#pragma unroll
+                for (int s = 0; s < CH / 8; ++s) {
+                    h8 ahi, alo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = a[8 * s + j] * 16.0f;
+                        const _Float16 hi = (_Float16)v;
+                        ahi[j] = hi;
+                        alo[j] = (_Float16)(v - (float)hi);
+                    }
+                    const int o = c + 8 * s;
+                    const h8 bhi = first ? __builtin_bit_cast(h8, v4f{b0[o], b0[o + 1], b0[o + 2], b0[o + 3]})
+                                         : __builtin_bit_cast(h8, v4f{b1[o], b1[o + 1], b1[o + 2], b1[o + 3]});
+                    const h8 blo = first ? __builtin_bit_cast(h8, v4f{b0[o + 4], b0[o + 5], b0[o + 6], b0[o + 7]})
+                                         : __builtin_bit_cast(h8, v4f{b1[o + 4], b1[o + 5], b1[o + 6], b1[o + 7]});
+                    acc = mfma16(ahi, bhi, acc);
+                    acc = mfma16(ahi, blo, acc);
+                    acc = mfma16(alo, bhi, acc);
+                }
+            } else if (first) {
 #pragma unroll
                 for (int i = 0; i < CH; ++i) acc = mfma32(a[i], b0[c + i], acc);
             } else {
 #pragma unroll
                 for (int i = 0; i < CH; ++i) acc = mfma32(a[i], b1[c + i], acc);
             }
+        }
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= (1.0f / 4096.0f);
         }
         epi(mt, nt, r, h, acc);
     }
@@ -205,7 +232,8 @@ __device__ __forceinline__ float drop_apply(float v, uint8_t keep, float keep_pr
 // x [batch][N][V]; temb [tstride ? batch : 1][64]; mask [mstride ? batch : 1][N][N];
 // concat [rows_pad][L*64] (row = graph*N + node); attn0 [batch][H][N][N] or null.
 // SPLIT: concat rows are written as split-pair fp16 rows (dnag_gemm16.hip.h) for the fp16-MFMA head GEMM.
-template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false, bool DROP = false, bool SPLIT = false>
+// F16: the four linears of every layer run on the split-arithmetic fp16 MFMAs (weights from the frag16 copy at delta16).
+template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false, bool DROP = false, bool SPLIT = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict__ P, const CateLayout lay,
                                                          const float *__restrict__ x, const float *__restrict__ temb,
                                                          int tstride, const float *__restrict__ mask, int mstride,
@@ -237,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     const int ft_o = JobSplit<NT_O, MT, 4>::first_tile(wave);
     const int ft_f1 = JobSplit<NT_F1, MT, 4>::first_tile(wave);
     const int ft_f2 = JobSplit<NT_F2, MT, 4>::first_tile(wave);
-    if (ft_qkv >= 0) load_w64(P + lay.layer0 + lay.l_wqkv, ft_qkv, bP);
+    const size_t wofs = F16 ? lay.delta16 : 0;     // weight matrices come from the fp16 fragment copy
+    if (ft_qkv >= 0) load_w64(P + lay.layer0 + wofs + lay.l_wqkv, ft_qkv, bP);
 
     {   // debug stagger experiment: bits 8-9 select which blocks sleep, bits 10-17 how long (x 8K cycles / 16)
         const int mode = (dbg_skip >> 8) & 3, amt = (dbg_skip >> 10) & 255;
@@ -290,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         if constexpr (DROP) KL = dm.keep + dm.rows * D + ((size_t)l * dm.rows + (size_t)g0 * N) * dm.per_layer;
         // ---- QKV = LN1(h) Wqkv'^T + bqkv' --------------------------------------------------------
         if (!(dbg_skip & 1)) {
-            const float *W = LP + lay.l_wqkv, *bias = LP + lay.l_bqkv;
-            run_jobs2<D, NT_QKV, MT, 4, true>(
+            const float *W = LP + wofs + lay.l_wqkv, *bias = LP + lay.l_bqkv;
+            run_jobs2<D, NT_QKV, MT, 4, true, F16>(
                 hbuf, HS, bP, bQ, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
@@ -305,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                 });
         }
         constexpr bool PF_ATT = N <= 8;   // larger graphs need the registers for the attention rows
-        if (PF_ATT && ft_o >= 0) load_w64(LP + lay.l_wo, ft_o, bP);   // lands while attention runs
+        if (PF_ATT && ft_o >= 0) load_w64(LP + wofs + lay.l_wo, ft_o, bP);   // lands while attention runs
         __syncthreads();
         // ---- attention per (graph, head, query) ---------------------------------------------------
         if (!(dbg_skip & 2))
@@ -355,12 +384,12 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
 #pragma unroll
             for (int e = 0; e < DK; e += 4) *reinterpret_cast<v4f *>(op + e) = v4f{o[e], o[e + 1], o[e + 2], o[e + 3]};
         }
-        if (!PF_ATT && ft_o >= 0) load_w64(LP + lay.l_wo, ft_o, bP);
+        if (!PF_ATT && ft_o >= 0) load_w64(LP + wofs + lay.l_wo, ft_o, bP);
         __syncthreads();
         // ---- h += attn Wo^T + bo ------------------------------------------------------------------
         if (!(dbg_skip & 4)) {
-            const float *W = LP + lay.l_wo, *bias = LP + lay.l_bo;
-            run_jobs2<D, NT_O, MT, 4, false>(
+            const float *W = LP + wofs + lay.l_wo, *bias = LP + lay.l_bo;
+            run_jobs2<D, NT_O, MT, 4, false, F16>(
                 qkv, QS, bP, bP, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
@@ -377,17 +406,17 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     }
                 });
         }
-        if (ft_f1 >= 0) load_w64(LP + lay.l_w1, ft_f1, bQ);
+        if (ft_f1 >= 0) load_w64(LP + wofs + lay.l_w1, ft_f1, bQ);
         if (ft_f2 >= 0) {
-            const float *w = LP + lay.l_w2;
+            const float *w = LP + wofs + lay.l_w2;
             asm volatile("" : "+s"(w));
             load_frag<DFF>(w, ft_f2, bR);
         }
         __syncthreads();
         // ---- hidden = relu(LN2(h) W1'^T + b1') -----------------------------------------------------
         if (!(dbg_skip & 8)) {
-            const float *W = LP + lay.l_w1, *bias = LP + lay.l_b1;
-            run_jobs2<D, NT_F1, MT, 4, true>(
+            const float *W = LP + wofs + lay.l_w1, *bias = LP + lay.l_b1;
+            run_jobs2<D, NT_F1, MT, 4, true, F16>(
                 hbuf, HS, bQ, bP, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                     const int col = nt * 32 + r;
@@ -402,12 +431,12 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     }
                 });
         }
-        if (l + 1 < L && ft_qkv >= 0) load_w64(LP + lay.layer_stride + lay.l_wqkv, ft_qkv, bP);   // next layer's first tile
+        if (l + 1 < L && ft_qkv >= 0) load_w64(LP + wofs + lay.layer_stride + lay.l_wqkv, ft_qkv, bP);   // next layer's first tile
         __syncthreads();
         // ---- h += hidden W2^T + b2 ----------------------------------------------------------------
         if (!(dbg_skip & 16)) {
-            const float *W = LP + lay.l_w2, *bias = LP + lay.l_b2;
-            run_jobs2<DFF, NT_F2, MT, 4, false>(
+            const float *W = LP + wofs + lay.l_w2, *bias = LP + lay.l_b2;
+            run_jobs2<DFF, NT_F2, MT, 4, false, F16>(
                 qkv, QS, bR, bR,
                 [&](int nt, int, int, float (&b)[DFF / 2]) { load_frag<DFF>(W, nt, b); },
                 [&](int mt, int nt, int r, int h, const f32x16 &acc) {

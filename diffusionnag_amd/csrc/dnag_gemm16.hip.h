@@ -20,8 +20,6 @@
 #include "dnag_common.h"
 #include "dnag_head.hip.h"
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 #define SPLIT_SA 16.0f        // activation scale
 #define SPLIT_SW 256.0f       // weight scale
 #define SPLIT_OUT_INV (1.0f / (SPLIT_SA * SPLIT_SW))
@@ -47,8 +45,6 @@ static inline void split_pack(const float *W, size_t rows, size_t K, float *out)
 }
 
 #ifdef __HIPCC__
-__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
-
 // split-pair activation rows -> fp32 (tests and the concat_out of dnag_cate_forward)
 __global__ void unsplit_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows, int K) {
     const _Float16 *p = reinterpret_cast<const _Float16 *>(in);

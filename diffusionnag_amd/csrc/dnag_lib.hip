@@ -133,12 +133,16 @@ static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *
             o += d * d + d;
         }
         frag_pack(tmp.data(), 3 * d, d, d, LP + y.l_wqkv);
-        frag_pack(s + o, d, d, d, LP + y.l_wo); o += d * d;
+        frag16_pack(tmp.data(), 3 * d, d, d, LP + y.delta16 + y.l_wqkv);
+        frag_pack(s + o, d, d, d, LP + y.l_wo);
+        frag16_pack(s + o, d, d, d, LP + y.delta16 + y.l_wo); o += d * d;
         memcpy(LP + y.l_bo, s + o, d * sizeof(float)); o += d;
         const float *ln2g = s + o, *ln2b = s + o + d; o += 2 * d;
         fold_ln(s + o, s + o + dff * d, ln2g, ln2b, dff, d, tmp.data(), LP + y.l_b1); o += dff * d + dff;
         frag_pack(tmp.data(), dff, d, d, LP + y.l_w1);
-        frag_pack(s + o, d, dff, dff, LP + y.l_w2); o += d * dff;
+        frag16_pack(tmp.data(), dff, d, d, LP + y.delta16 + y.l_w1);
+        frag_pack(s + o, d, dff, dff, LP + y.l_w2);
+        frag16_pack(s + o, d, dff, dff, LP + y.delta16 + y.l_w2); o += d * dff;
         memcpy(LP + y.l_b2, s + o, d * sizeof(float)); o += d;
     }
     for (size_t l = 0; l < L; ++l) {   // encoder_f.norms.l
@@ -528,7 +532,7 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
                             const float *mask, int mstride, float *concat, float *attn0, int batch, hipStream_t st) {
     typedef EncGeom<N, G, 128> Ge;
     const size_t lds = Ge::lds_floats * sizeof(float);
-    auto kern = encoder_kernel<N, V, G, 8, 128, true, false, false, true>;   // concat in split-pair rows
+    auto kern = encoder_kernel<N, V, G, 8, 128, true, false, false, true, true>;   // split-arithmetic linears, concat in split-pair rows
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

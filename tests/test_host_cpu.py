@@ -106,18 +106,33 @@ def test_cate_pack_folds_layernorm_into_linear():
     f0 = layer0 + 12 * stride
     assert np.array_equal(packed[f0: f0 + 1536 * 768].astype(np.float32), sd["final.linears.0.weight"].numpy().ravel())
     # derived tables = the oracle's restatement of the reference constructors
-    n_split = 1536 * 768 + 1536 * 1536                 # split-pair copies of final.linears.{0,1} close the blob
-    tail = packed[-(8 * 64 + 32) - n_split: -n_split]
+    n_split = 1536 * 768 + 1536 * 1536                 # split-pair copies of final.linears.{0,1} ...
+    n_l16 = 12 * stride                                # ... and the fp16-fragment copy of the layer blocks close the blob
+    tail = packed[-(8 * 64 + 32) - n_split - n_l16: -n_split - n_l16]
     assert np.allclose(tail[: 8 * 64], O.positional_table(8, 64, False).numpy().ravel(), atol=0)
     assert np.allclose(tail[8 * 64:], _cate.timestep_frequencies(64).numpy(), atol=0)
     # split-pair rows (csrc/dnag_gemm16.hip.h): groups of 8 values = 8 fp16 hi then 8 fp16 lo of 256 w; hi + lo
     # reproduces the fp32 weight to 22 significant bits
-    raw = model._pack_host(model._state_flat().contiguous()).numpy()[-n_split:]
+    raw_all = model._pack_host(model._state_flat().contiguous()).numpy()
+    raw = raw_all[-n_split - n_l16: -n_l16]
     halves = raw[: 1536 * 768].view(np.float16).reshape(1536, 768 // 8, 2, 8).astype(np.float64)
     w0 = sd["final.linears.0.weight"].double().numpy()
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 768) / 256.0
     assert np.abs(rec - w0).max() <= 2.0 ** -21 * np.abs(w0).max()
     assert np.array_equal(halves[:, :, 0, :].reshape(1536, 768), (w0 * 256).astype(np.float16).astype(np.float64))
+    # fp16 fragment copy of layer 7's Wo (csrc/dnag_common.h: frag16_pack): chunk q of lane l holds the hi (q even) or lo
+    # (q odd) halves of 256 W[nt*32 + r][h*32 + 8(q>>1) .. +7]
+    l16 = raw_all[-n_l16:]
+    wo_off = 7 * stride + 3 * d * d + 3 * d
+    fr = l16[wo_off: wo_off + d * d].view(np.float16).reshape(2, 8, 64, 8).astype(np.float64)      # [nt][q][lane][j]
+    Wo = sd["graph_encoder.encoder_f.layers.7.self_attn.attn.linears.3.weight"].double().numpy()
+    rec = np.zeros((64, 64))
+    for nt in range(2):
+        for q in range(8):
+            for lane in range(64):
+                r_, h_ = lane & 31, lane >> 5
+                rec[nt * 32 + r_, h_ * 32 + 8 * (q >> 1): h_ * 32 + 8 * (q >> 1) + 8] += fr[nt, q, lane]
+    assert np.abs(rec / 256.0 - Wo).max() <= 2.0 ** -21 * np.abs(Wo).max()
 
 
 def test_predictor_pack_transposes():
@@ -165,7 +180,7 @@ def test_predictor_cate_pack_layout():
     assert np.array_equal(packed[f0: f0 + Hd * F], sdp["final.linears.0.weight"].numpy().ravel())
     tab_end = f0 + Hd * F + Hd + Hd * Hd + Hd + al4(V * Hd) + al4(V) + al4(20 * D_) + al4(D_ // 2)
     assert not packed[tab_end - al4(D_ // 2) - al4(20 * D_): tab_end - al4(D_ // 2)].any()      # no positional table
-    enc_total = tab_end + Hd * F + Hd * Hd          # split-pair copies of final.linears.{0,1} (unused by this surrogate)
+    enc_total = tab_end + Hd * F + Hd * Hd + L * stride   # split-pair / fp16-fragment copies (unused by this surrogate)
     # backward operands of layer 1: Wo^T and W2^T, fragment-major
     per_layer = 32 * 2 * 3 * D_ + 32 * 2 * D_ + 32 * 2 * dff + 32 * D_      # frag_floats(rows, K) = ceil(rows/32)*32*K
     b1 = enc_total + per_layer
