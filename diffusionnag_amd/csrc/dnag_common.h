@@ -133,6 +133,8 @@ struct PredLayout {
     size_t p0_at;                 // transposed arch part [lh][hs]
     size_t p2_w, p2_b;            // pred_fc.2 [hs], [1]
     size_t freq;                  // [g/2]
+    size_t delta16;               // P + delta16 + (offset of w1b .. fc1b): the same fragment-major matrices as fp16 hi/lo
+                                  // fragments scaled by 256 (frag16_pack) for the split-arithmetic MFMAs
     size_t total;
 };
 
@@ -163,6 +165,8 @@ static inline __host__ __device__ PredLayout pred_layout(const dnag_pred_dims &c
     y.p2_w = o; o += align4(hs);
     y.p2_b = o; o += 4;
     y.freq = o; o += align4(g / 2);
+    y.delta16 = o - y.w1b[0];
+    o += (y.fc1b + frag_floats(g, lh)) - y.w1b[0];
     y.total = o;
     return y;
 }
@@ -246,6 +250,17 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// power of two s with s * amax in [512, 1024) (1 for amax = 0; capped so that products of two scales stay finite):
+// operand scale of the split-arithmetic MFMAs when the magnitude of an operand is only known at run time
+__device__ __forceinline__ float pow2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.0f;
+    int e;
+    frexpf(amax, &e);
+    int k = 10 - e;
+    k = k > 40 ? 40 : (k < -40 ? -40 : k);
+    return ldexpf(1.0f, k);
+}
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }

@@ -15,8 +15,11 @@
 // Jobs (nt, mt) are dealt in contiguous chunks to the NW waves; B fragments stay in registers
 // while nt does not change.
 // ---------------------------------------------------------------------------------------------
-template <int K, int MT, int NW, typename BLoad, typename AXf, typename Epi>
-__device__ __forceinline__ void run_jobs(int ntiles, const float *A, int as, BLoad bload, AXf axf, Epi epi) {
+// F16: split-arithmetic MFMAs (dnag_gemm16.hip.h): `bload` fills the B registers with frag16_pack fragments (fp16
+// hi/lo of 256 W); every A value is scaled by the power of two `sa`, split, and three v_mfma_f32_32x32x16_f16 per
+// 8 k values replace eight v_mfma_f32_32x32x2_f32; the accumulator is scaled back before the epilogue.
+template <int K, int MT, int NW, bool F16 = false, typename BLoad, typename AXf, typename Epi>
+__device__ __forceinline__ void run_jobs(int ntiles, const float *A, int as, BLoad bload, AXf axf, Epi epi, float sa = 16.0f) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -36,14 +39,41 @@ __device__ __forceinline__ void run_jobs(int ntiles, const float *A, int as, BLo
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
         const float *ap = A + (size_t)(mt * 32 + r) * as + h * (K / 2);
+        if constexpr (F16) {
+            static_assert(K % 16 == 0, "8 k values per lane half and step");
 #pragma unroll
-        for (int q = 0; q < K / 8; ++q) {
-            v4f a4 = *reinterpret_cast<const v4f *>(ap + 4 * q);
-            a4 = axf(a4, mt * 32 + r);
-            acc = mfma32(a4.x, b[4 * q + 0], acc);
-            acc = mfma32(a4.y, b[4 * q + 1], acc);
-            acc = mfma32(a4.z, b[4 * q + 2], acc);
-            acc = mfma32(a4.w, b[4 * q + 3], acc);
+            for (int s = 0; s < K / 16; ++s) {
+                v4f a0 = *reinterpret_cast<const v4f *>(ap + 8 * s);
+                v4f a1 = *reinterpret_cast<const v4f *>(ap + 8 * s + 4);
+                a0 = axf(a0, mt * 32 + r);
+                a1 = axf(a1, mt * 32 + r);
+                h8 ahi, alo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float v = (e < 4 ? a0[e] : a1[e - 4]) * sa;
+                    const _Float16 hi = (_Float16)v;
+                    ahi[e] = hi;
+                    alo[e] = (_Float16)(v - (float)hi);
+                }
+                const h8 bhi = __builtin_bit_cast(h8, v4f{b[8 * s], b[8 * s + 1], b[8 * s + 2], b[8 * s + 3]});
+                const h8 blo = __builtin_bit_cast(h8, v4f{b[8 * s + 4], b[8 * s + 5], b[8 * s + 6], b[8 * s + 7]});
+                acc = mfma16(ahi, bhi, acc);
+                acc = mfma16(ahi, blo, acc);
+                acc = mfma16(alo, bhi, acc);
+            }
+            const float inv = 1.0f / (sa * 256.0f);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= inv;
+        } else {
+#pragma unroll
+            for (int q = 0; q < K / 8; ++q) {
+                v4f a4 = *reinterpret_cast<const v4f *>(ap + 4 * q);
+                a4 = axf(a4, mt * 32 + r);
+                acc = mfma32(a4.x, b[4 * q + 0], acc);
+                acc = mfma32(a4.y, b[4 * q + 1], acc);
+                acc = mfma32(a4.z, b[4 * q + 2], acc);
+                acc = mfma32(a4.w, b[4 * q + 3], acc);
+            }
         }
         epi(mt, nt, r, h, acc);
     }

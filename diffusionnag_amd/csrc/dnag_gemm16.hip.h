@@ -90,16 +90,6 @@ struct SplitF32Args {
     float *amax_out;                  // optional: max |C| (float bits, atomicMax) for a later GEMM's operand scale
 };
 
-// power of two s with s * amax in [512, 1024) (1 for amax = 0; capped so that products of two scales stay finite)
-__device__ __forceinline__ float pow2_scale(float amax) {
-    if (!(amax > 0.f)) return 1.0f;
-    int e;
-    frexpf(amax, &e);
-    int k = 10 - e;
-    k = k > 40 ? 40 : (k < -40 ? -40 : k);
-    return ldexpf(1.0f, k);
-}
-
 // *out = max(*out, max |x[i]|) as float bits (non-negative floats order like unsigned integers); *out starts at 0
 __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, size_t n, float *__restrict__ out) {
     __shared__ float sh[256];

@@ -189,19 +189,23 @@ extern "C" int dnag_pred_pack(const dnag_pred_dims *c, const float *s, const flo
             const float *W = s + o; o += in * g;   // [in][g]
             if (l == 0) memcpy(out + (w ? y.w2_0 : y.w1_0), W, in * g * sizeof(float));
             frag_pack(W, in, g, g, out + (w ? y.w2b[l] : y.w1b[l]));
+            frag16_pack(W, in, g, g, out + y.delta16 + (w ? y.w2b[l] : y.w1b[l]));
             if (l > 0) {
                 for (size_t i = 0; i < in; ++i)
                     for (size_t k = 0; k < g; ++k) tr[k * in + i] = W[i * g + k];
                 frag_pack(tr.data(), g, in, in, out + (w ? y.w2f[l] : y.w1f[l]));
+                frag16_pack(tr.data(), g, in, in, out + y.delta16 + (w ? y.w2f[l] : y.w1f[l]));
             }
         }
     }
     {
         const float *W = s + o; o += lh * g;   // fc1 [lh][g]
         frag_pack(W, lh, g, g, out + y.fc1f);
+        frag16_pack(W, lh, g, g, out + y.delta16 + y.fc1f);
         for (size_t i = 0; i < lh; ++i)
             for (size_t k = 0; k < g; ++k) tr[k * lh + i] = W[i * g + k];
         frag_pack(tr.data(), g, lh, lh, out + y.fc1b);
+        frag16_pack(tr.data(), g, lh, lh, out + y.delta16 + y.fc1b);
     }
     memcpy(out + y.t1_w, s + o, 4 * g * g * sizeof(float)); o += 4 * g * g;
     memcpy(out + y.t1_b, s + o, 4 * g * sizeof(float)); o += 4 * g;

@@ -74,6 +74,20 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     const int tid = threadIdx.x;
     const int g0 = blockIdx.x * G;
 
+    // Split-arithmetic MFMAs (dnag_gemm16.hip.h): every GEMM phase reads fp16 hi/lo weight fragments (P + delta16) and
+    // splits its A operand with a power-of-two scale derived from the operand's largest magnitude in this workgroup
+    // (backward operands are gradients of unknown size): the producers of U1 / U2 leave max |value| of phase k in amaxv[k].
+    __shared__ unsigned int amaxv[24];
+    if (tid < 24) amaxv[tid] = 0u;
+    int phase = 0;
+    auto note_max = [&](float m, int ph) {       // wave maximum -> one LDS atomic per wave
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((tid & 63) == 0) atomicMax(&amaxv[ph], __float_as_uint(m));
+    };
+    auto phase_scale = [&](int ph) { return pow2_scale(__uint_as_float(amaxv[ph])); };
+    const float *P16 = P + lay.delta16;
+
     // ---- inputs ---------------------------------------------------------------------------------
     for (int i = tid; i < R * XS; i += NT) {
         const int r = i / XS, v = i - r * XS;
@@ -157,7 +171,8 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
 
     auto id_xf = [](v4f a, int) { return a; };
     // adjacency mixing, one (graph, column) item per thread: the 8 rows of the column stay in registers
-    auto mix_fwd = [&]() {   // U1 = A1 H, U2 = A2 H
+    auto mix_fwd = [&](int ph) {   // U1 = A1 H, U2 = A2 H
+        float vmax = 0.f;
         for (int i = tid; i < G * GH; i += NT) {
             const int g = i / GH, c = i - g * GH;
             float hv[N];
@@ -173,12 +188,15 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                 for (int j = 0; j < N; ++j) { u1 = fmaf(a1[j], hv[j], u1); u2 = fmaf(a2[j], hv[j], u2); }
                 U1[(g * N + n) * HS + c] = u1;
                 U2[(g * N + n) * HS + c] = u2;
+                vmax = fmaxf(vmax, fmaxf(fabsf(u1), fabsf(u2)));
             }
         }
+        note_max(vmax, ph);
     };
     // P1 = A1^T (1/2 dH . m1), P2 = A2^T (1/2 dH . m2) into U1, U2
-    auto mix_bwd = [&](int l) {
+    auto mix_bwd = [&](int l, int ph) {
         const uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
+        float vmax = 0.f;
         for (int i = tid; i < G * GH; i += NT) {
             const int g = i / GH, c = i - g * GH;
             const int nt = c >> 5, bit = c & 31;
@@ -201,8 +219,10 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             for (int n = 0; n < N; ++n) {
                 U1[(g * N + n) * HS + c] = p1[n];
                 U2[(g * N + n) * HS + c] = p2[n];
+                vmax = fmaxf(vmax, fmaxf(fabsf(p1[n]), fabsf(p2[n])));
             }
         }
+        note_max(vmax, ph);
     };
     auto load_b144 = [&](const float *F, int nt, int, int, float (&b)[GH / 2]) {   // fragment-major, zero padded
         load_frag<GH>(F, nt, b);
@@ -210,17 +230,19 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
 
     // ---- layers 1 .. L-1 forward -----------------------------------------------------------------
     for (int l = 1; l < L; ++l) {
-        if (!(dbg_skip & 2)) mix_fwd();
+        const int ph = phase++;
+        if (!(dbg_skip & 2)) mix_fwd(ph);
         __syncthreads();
-        const float *W1t = P + lay.w1f[l], *W2t = P + lay.w2f[l];   // fragment-major W^T [out][in]
+        const float sa = phase_scale(ph);
+        const float *W1t = P16 + lay.w1f[l], *W2t = P16 + lay.w2f[l];   // fp16 fragments of W^T [out][in]
         uint32_t *bl = bits + (size_t)l * 2 * R * PRED_NT;
         if (!(dbg_skip & 4)) {
             f32x16 acc1;
             // each wave owns one (column tile, row tile); Z1 and Z2 back to back with the same registers
-            run_jobs<GH, MT, PRED_NW>(
+            run_jobs<GH, MT, PRED_NW, true>(
                 PRED_NT, U1, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W1t, nt, r, h, b); }, id_xf,
-                [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
-            run_jobs<GH, MT, PRED_NW>(
+                [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; }, sa);
+            run_jobs<GH, MT, PRED_NW, true>(
                 PRED_NT, U2, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W2t, nt, r, h, b); }, id_xf,
                 [&](int mt, int nt, int r, int h, const f32x16 &acc2) {
                     const int col = nt * 32 + r;
@@ -234,26 +256,34 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                         }
                         if (col < GH) Hb[row * HS + col] = (fmaxf(acc1[i], 0.f) + fmaxf(acc2[i], 0.f)) / 2.f;
                     }
-                });
+                }, sa);
         }
         __syncthreads();
     }
 
     // ---- head forward: graphs become the rows 0..G-1 of a 32-row MFMA tile ---------------------------
     if (!(dbg_skip & 8)) {
+        const int ph = phase++;
+        float vmax = 0.f;
         for (int i = tid; i < G * GH; i += NT) {
             const int g = i / GH, c = i - g * GH;
             float s = 0.f;
 #pragma unroll
             for (int n = 0; n < N; ++n) s += Hb[(g * N + n) * HS + c];
             const int gg = (g0 + g < batch) ? g0 + g : 0;
-            U1[g * HS + c] = s / (float)N + temb[(size_t)(tstride ? gg : 0) * GH + c];   // digcn_meta.py:19-22, :125
+            const float pv = s / (float)N + temb[(size_t)(tstride ? gg : 0) * GH + c];   // digcn_meta.py:19-22, :125
+            U1[g * HS + c] = pv;
+            vmax = fmaxf(vmax, fabsf(pv));
         }
+        // rows G .. 31 of the MFMA tile hold stale values of the last mixing: an MFMA output row depends on its own A row
+        // only, and the epilogue drops those rows, so they take no part in the scale (an overflow there is harmless)
+        note_max(vmax, ph);
         __syncthreads();
+        const float sa = phase_scale(ph);
         // a = Wfc1 p  (fc1 [LH][GH]: rows K-contiguous) -> U2[g][0..127]
-        run_jobs<GH, 1, PRED_NW>(
+        run_jobs<GH, 1, PRED_NW, true>(
             LH / 32, U1, HS,
-            [&](int nt, int, int, float (&b)[GH / 2]) { load_frag<GH>(P + lay.fc1f, nt, b); },
+            [&](int nt, int, int, float (&b)[GH / 2]) { load_frag<GH>(P16 + lay.fc1f, nt, b); },
             id_xf,
             [&](int, int nt, int r, int h, const f32x16 &acc) {
 #pragma unroll
@@ -261,7 +291,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                     const int row = acc_row(i, h);
                     if (row < G) U2[row * HS + nt * 32 + r] = acc[i];
                 }
-            });
+            }, sa);
         __syncthreads();
         for (int i = tid; i < G * hs; i += NT) {   // tanh(W0a a + c0)  (p0_at [LH][hs])
             const int g = i / hs, j = i - g * hs;
@@ -289,6 +319,8 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             tv[g * TS + j] = P[lay.p2_w + j] * (1.f - t * t);
         }
         __syncthreads();
+        const int ph = phase++;
+        float vmax = 0.f;
         for (int i = tid; i < G * LH; i += NT) {   // da[o] = sum_j W0[j][nz + o] dpre[j] -> U1[g][0..127]
             const int g = i / LH, o = i - g * LH;
             const float *w = P + lay.p0_w + nz + o;
@@ -296,12 +328,15 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
 #pragma unroll 8
             for (int j = 0; j < hs; ++j) acc = fmaf(w[(size_t)j * (nz + LH)], tv[g * TS + j], acc);
             U1[g * HS + o] = acc;
+            vmax = fmaxf(vmax, fabsf(acc));
         }
+        note_max(vmax, ph);
         __syncthreads();
+        const float sa = phase_scale(ph);
         // dp = Wfc1^T da  (fc1t [GH][LH]: rows K-contiguous);  dH_L[n][c] = dp[c] / N for every node n
-        run_jobs<LH, 1, PRED_NW>(
+        run_jobs<LH, 1, PRED_NW, true>(
             PRED_NT, U1, HS,
-            [&](int nt, int, int, float (&b)[LH / 2]) { load_frag<LH>(P + lay.fc1b, nt, b); },
+            [&](int nt, int, int, float (&b)[LH / 2]) { load_frag<LH>(P16 + lay.fc1b, nt, b); },
             id_xf,
             [&](int, int nt, int r, int h, const f32x16 &acc) {
                 const int col = nt * 32 + r;
@@ -314,21 +349,23 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                         for (int n = 0; n < N; ++n) Hb[(g * N + n) * HS + col] = d;
                     }
                 }
-            });
+            }, sa);
     }
     __syncthreads();
 
     // ---- layers L-1 .. 1 backward: dH_l = P1 W1^T + P2 W2^T  (B rows = W[in][:] K-contiguous) ------
     for (int l = L - 1; l >= 1; --l) {
-        if (!(dbg_skip & 32)) mix_bwd(l);
+        const int ph = phase++;
+        if (!(dbg_skip & 32)) mix_bwd(l, ph);
         __syncthreads();
-        const float *W1 = P + lay.w1b[l], *W2 = P + lay.w2b[l];   // fragment-major W [in][out]
+        const float sa = phase_scale(ph);
+        const float *W1 = P16 + lay.w1b[l], *W2 = P16 + lay.w2b[l];   // fp16 fragments of W [in][out]
         if (!(dbg_skip & 64)) {
             f32x16 acc1;
-            run_jobs<GH, MT, PRED_NW>(
+            run_jobs<GH, MT, PRED_NW, true>(
                 PRED_NT, U1, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W1, nt, r, h, b); }, id_xf,
-                [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
-            run_jobs<GH, MT, PRED_NW>(
+                [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; }, sa);
+            run_jobs<GH, MT, PRED_NW, true>(
                 PRED_NT, U2, HS, [&](int nt, int r, int h, float (&b)[GH / 2]) { load_b144(W2, nt, r, h, b); }, id_xf,
                 [&](int mt, int nt, int r, int h, const f32x16 &acc2) {
                     const int col = nt * 32 + r;
@@ -336,20 +373,22 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
 #pragma unroll
                         for (int i = 0; i < 16; ++i) Hb[(mt * 32 + acc_row(i, h)) * HS + col] = acc1[i] + acc2[i];
                     }
-                });
+                }, sa);
         }
         __syncthreads();
     }
     // ---- layer 0 backward: dx[r][v] = sum_c P1[r][c] W1[v][c] + P2[r][c] W2[v][c]  (one column tile) ----
-    if (!(dbg_skip & 32)) mix_bwd(0);
+    const int ph0 = phase++;
+    if (!(dbg_skip & 32)) mix_bwd(0, ph0);
     __syncthreads();
     if (!(dbg_skip & 128)) {
-        const float *W1 = P + lay.w1b[0], *W2 = P + lay.w2b[0];   // fragment-major [V -> 32][GH], one tile
+        const float sa = phase_scale(ph0);
+        const float *W1 = P16 + lay.w1b[0], *W2 = P16 + lay.w2b[0];   // fp16 fragments [V -> 32][GH], one tile
         f32x16 acc1;
-        run_jobs<GH, MT, PRED_NW>(
+        run_jobs<GH, MT, PRED_NW, true>(
             1, U1, HS, [&](int, int, int, float (&b)[GH / 2]) { load_frag<GH>(W1, 0, b); }, id_xf,
-            [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; });
-        run_jobs<GH, MT, PRED_NW>(
+            [&](int, int, int, int, const f32x16 &acc) { acc1 = acc; }, sa);
+        run_jobs<GH, MT, PRED_NW, true>(
             1, U2, HS, [&](int, int, int, float (&b)[GH / 2]) { load_frag<GH>(W2, 0, b); }, id_xf,
             [&](int mt, int, int r, int h, const f32x16 &acc2) {
                 if (r < V) {
@@ -359,6 +398,6 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                         if (g0 + row / N < batch) grad[((size_t)g0 * N + row) * V + r] = acc1[i] + acc2[i];
                     }
                 }
-            });
+            }, sa);
     }
 }
