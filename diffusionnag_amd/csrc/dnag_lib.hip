@@ -666,7 +666,7 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
     {   // encoder, saving what the backward pass needs
         typedef EncGeom<PC_N, PC_G, 32> Ge;
         const size_t lds = Ge::lds_floats * sizeof(float);
-        auto kern = encoder_kernel<PC_N, PC_V, PC_G, 2, 32, false, true>;
+        auto kern = encoder_kernel<PC_N, PC_V, PC_G, 2, 32, false, true, false, false, true>;   // saved activations, split-arithmetic linears
         static bool attr_set = false;
         if (!attr_set) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -989,8 +989,8 @@ static int launch_train_encoder(bool drop, int nblk, const float *P, const CateL
                                 int mstride, float *concat, int B, const EncSave &sv, const DropMasks &dm, hipStream_t st) {
     typedef EncGeom<8, G, 128> Ge;
     const size_t lds = Ge::lds_floats * sizeof(float);
-    auto k_drop = encoder_kernel<8, 7, G, 8, 128, true, true, true>;
-    auto k_nodrop = encoder_kernel<8, 7, G, 8, 128, true, true, false>;
+    auto k_drop = encoder_kernel<8, 7, G, 8, 128, true, true, true, false, true>;      // split-arithmetic linears
+    auto k_nodrop = encoder_kernel<8, 7, G, 8, 128, true, true, false, false, true>;
     static bool attr_set = false;
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_drop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

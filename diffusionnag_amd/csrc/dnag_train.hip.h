@@ -136,6 +136,21 @@ __device__ __forceinline__ size_t frag_at(size_t K, size_t row, size_t k) {
     return (((row >> 5) * (K / 8) + (kk >> 2)) * 64 + 32 * h + (row & 31)) * 4 + (kk & 3);
 }
 
+// half index of value (row, k) inside a frag16_pack matrix (dnag_common.h): hi at the returned index, lo 64 * 8 halves
+// further on (the next 16-byte chunk row of the same tile and step)
+__device__ __forceinline__ size_t frag16_at(size_t K, size_t row, size_t k) {
+    const size_t KH = K / 2, h = k / KH, kk = k - h * KH;
+    return (((row >> 5) * (K / 8) + 2 * (kk >> 3)) * 64 + 32 * h + (row & 31)) * 8 + (kk & 7);
+}
+__device__ __forceinline__ void frag16_put(float *base, size_t K, size_t row, size_t k, float w) {
+    _Float16 *o = reinterpret_cast<_Float16 *>(base);
+    const float v = w * 256.0f;
+    const _Float16 hi = (_Float16)v;
+    const size_t at = frag16_at(K, row, k);
+    o[at] = hi;
+    o[at + 64 * 8] = (_Float16)(v - (float)hi);
+}
+
 __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__restrict__ S, const CateStateLayout sl,
                                                                 float *__restrict__ P, const TrainLayout tl) {
     const int l = blockIdx.y;
@@ -143,6 +158,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
     const float *SL = S + sl.layer0 + (size_t)l * sl.layer_stride;
     float *LF = P + tl.enc.layer0 + (size_t)l * tl.enc.layer_stride;
     float *LB = P + tl.bl0 + (size_t)l * tl.bl_stride;
+    float *L16 = LF + tl.enc.delta16;      // fp16 fragment copy of the forward matrices (split-arithmetic forward)
     const size_t n_qkv = 3 * d * d, n_o = d * d, n_1 = dff * d, n_2 = d * dff;
     const size_t n_bias = 3 * d + d + dff + d + 2 * d;
     const size_t total = n_qkv + n_o + n_1 + n_2 + n_bias;
@@ -153,6 +169,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t srcw = which == 0 ? sl.s_wq : which == 1 ? sl.s_wk : sl.s_wv;
             const float v = SL[srcw + rk] * SL[sl.s_ln1g + k];
             LF[tl.enc.l_wqkv + frag_at(d, which * d + r, k)] = v;
+            frag16_put(L16 + tl.enc.l_wqkv, d, which * d + r, k, v);
             LB[tl.b_wqkvT + frag_at(3 * d, k, which * d + r)] = v;
             continue;
         }
@@ -161,6 +178,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t r = j / d, k = j - r * d;
             const float v = SL[sl.s_wo + j];
             LF[tl.enc.l_wo + frag_at(d, r, k)] = v;
+            frag16_put(L16 + tl.enc.l_wo, d, r, k, v);
             LB[tl.b_woT + frag_at(d, k, r)] = v;
             continue;
         }
@@ -169,6 +187,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t r = j / d, k = j - r * d;
             const float v = SL[sl.s_w1 + j] * SL[sl.s_ln2g + k];
             LF[tl.enc.l_w1 + frag_at(d, r, k)] = v;
+            frag16_put(L16 + tl.enc.l_w1, d, r, k, v);
             LB[tl.b_w1T + frag_at(dff, k, r)] = v;
             continue;
         }
@@ -177,6 +196,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t r = j / dff, k = j - r * dff;
             const float v = SL[sl.s_w2 + j];
             LF[tl.enc.l_w2 + frag_at(dff, r, k)] = v;
+            frag16_put(L16 + tl.enc.l_w2, dff, r, k, v);
             LB[tl.b_w2T + frag_at(d, k, r)] = v;
             continue;
         }
