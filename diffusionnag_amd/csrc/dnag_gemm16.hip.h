@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, 
 // FUSE_V > 0 (final.linears.1 of the score network): the MFMA operands swap roles, so that a lane holds ONE row of
 // the batch and its registers 16 output columns, and the epilogue applies final.linears.2 (W3 [FUSE_V][Nout],
 // cate.py:55-73) to the ELU output in registers: parts[tn][row][v] = sum over this block's 256 columns of
-// elu(...)[row][col] W3[v][col], summed in a fixed order (lane, lane half, the 4 waves along N).  The 1536-wide
+// elu(...)[row][col] W3[v][col], again on split-arithmetic MFMAs, the 4 waves along N summed in a fixed order.  The 1536-wide
 // hidden activation never reaches HBM; the exit kernel adds the Nout / 256 partial sums and the bias.  C is unused.
 template <int ACT, bool OUT_SPLIT, int TAG, int FUSE_V = 0, bool IN_F32 = false>
 __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restrict__ A, const float *__restrict__ W,
@@ -267,37 +267,63 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
         for (int i = tid; i < V * BN; i += 512) { const int v = i / BN, c = i - v * BN; w3s[i] = W3[(size_t)v * Nout + tn * BN + c]; }
         for (int i = tid; i < BN; i += 512) b1s[i] = bias ? bias[tn * BN + i] : 0.f;
         __syncthreads();
+        // final.linears.2 on the matrix cores too: P[v][row] = sum_col W3[v][col] x[col][row] as 32x32x16 fp16 MFMAs in
+        // the same split arithmetic (W3 scaled by SPLIT_SW, x by SPLIT_SA).  A lane's 16 accumulator registers of one
+        // tile all belong to its batch row, so registers 8s .. 8s+7 ARE its B fragment of step s; the A fragment holds
+        // W3 at the columns those registers stand for (rows >= V of the 32-row operand are zero).
+        h8 w3h[2][2], w3l[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                v4f wa = {0.f, 0.f, 0.f, 0.f}, wb = {0.f, 0.f, 0.f, 0.f};
+                if (r < V) {
+                    const float *p = w3s + r * BN + wn * 64 + t * 32 + 16 * s2 + 4 * h;
+                    wa = *reinterpret_cast<const v4f *>(p);
+                    wb = *reinterpret_cast<const v4f *>(p + 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    _Float16 hi, lo;
+                    split16(wa[u], SPLIT_SW, hi, lo);
+                    w3h[t][s2][u] = hi; w3l[t][s2][u] = lo;
+                    split16(wb[u], SPLIT_SW, hi, lo);
+                    w3h[t][s2][4 + u] = hi; w3l[t][s2][4 + u] = lo;
+                }
+            }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float part[V];
+            f32x16 pa;
 #pragma unroll
-            for (int v = 0; v < V; ++v) part[v] = 0.f;
+            for (int e = 0; e < 16; ++e) pa[e] = 0.f;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int c0 = wn * 64 + t * 32 + 8 * q + 4 * h;        // columns of registers 4q .. 4q+3
-                    const v4f b4 = *reinterpret_cast<const v4f *>(b1s + c0);
-                    float hv[4];
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    h8 xh, xl;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float x = fmaf(acc[i][t][4 * q + u], SPLIT_OUT_INV, b4[u]);
-                        if (ACT == ACT_ELU) x = x > 0.f ? x : __expf(x) - 1.0f;
-                        hv[u] = x;
-                    }
+                    for (int q = 0; q < 2; ++q) {
+                        const int c0 = wn * 64 + t * 32 + 16 * s2 + 8 * q + 4 * h;     // columns of registers 8 s2 + 4q ..
+                        const v4f b4 = *reinterpret_cast<const v4f *>(b1s + c0);
 #pragma unroll
-                    for (int v = 0; v < V; ++v) {
-                        const v4f w4 = *reinterpret_cast<const v4f *>(w3s + v * BN + c0);
-                        part[v] = fmaf(hv[0], w4.x, part[v]); part[v] = fmaf(hv[1], w4.y, part[v]);
-                        part[v] = fmaf(hv[2], w4.z, part[v]); part[v] = fmaf(hv[3], w4.w, part[v]);
+                        for (int u = 0; u < 4; ++u) {
+                            float x = fmaf(acc[i][t][8 * s2 + 4 * q + u], SPLIT_OUT_INV, b4[u]);
+                            if (ACT == ACT_ELU) x = x > 0.f ? x : __expf(x) - 1.0f;
+                            _Float16 hi, lo;
+                            split16(x, SPLIT_SA, hi, lo);
+                            xh[4 * q + u] = hi; xl[4 * q + u] = lo;
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);      // keep the W3 reads of later columns from piling up in registers
+                    pa = mfma16(w3h[t][s2], xh, pa);
+                    pa = mfma16(w3l[t][s2], xh, pa);
+                    pa = mfma16(w3h[t][s2], xl, pa);
                 }
+            // lane (row r, half h) holds P[v][row] for v = acc_row(e, h) in register e
+            static_assert(V <= 32, "one 32-row MFMA operand of W3");
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-                part[v] += __shfl_xor(part[v], 32);                        // the other lane half holds the other columns
-                if (h == 0) red[(wn * BM + wm * 128 + i * 32 + r) * V + v] = part[v];
-            }
+            for (int e = 0; e < 16; ++e)
+                if ((e & 3) + 8 * (e >> 2) < V && acc_row(e, h) < V)
+                    red[(wn * BM + wm * 128 + i * 32 + r) * V + acc_row(e, h)] = pa[e] * SPLIT_OUT_INV;
         }
         __syncthreads();
         float *dst = parts + ((size_t)tn * M + (size_t)tm * BM) * V;
