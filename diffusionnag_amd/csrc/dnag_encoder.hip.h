@@ -92,10 +92,13 @@ __device__ __forceinline__ void load_row(const float *p, float (&b)[KH]) {
 // load instruction of the wave reads one contiguous KiB.
 template <int K>
 __device__ __forceinline__ void load_frag(const float *F, int nt, float (&b)[K / 2]) {
+    // explicit global address space: a pointer that went through the opaque asm of the prefetch lambdas would otherwise
+    // be loaded with flat instructions, which count on lgkmcnt too, so every LDS wait would also wait for the prefetch
+    typedef const __attribute__((address_space(1))) v4f *gv4p;
     const float *p = F + ((size_t)nt * (K / 8) * 64 + (threadIdx.x & 63)) * 4;
 #pragma unroll
     for (int q = 0; q < K / 8; ++q) {
-        const v4f v = *reinterpret_cast<const v4f *>(p + (size_t)q * 256);
+        const v4f v = *(gv4p)(p + (size_t)q * 256);
         b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
     }
 }
