@@ -388,20 +388,21 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                     acc = fmaf(q[e], v4.x, acc); acc = fmaf(q[e + 1], v4.y, acc);
                     acc = fmaf(q[e + 2], v4.z, acc); acc = fmaf(q[e + 3], v4.w, acc);
                 }
-                acc = acc / sqrtf((float)DK);
+                acc = acc * (1.0f / sqrtf((float)DK));    // constant-folded reciprocal
                 if (maskb[(g * N + i) * N + j] == 0.f) acc = -1e9f;
                 s[j] = acc;
                 mx = fmaxf(mx, acc);
             }
             float den = 0.f;
 #pragma unroll
-            for (int j = 0; j < N; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+            for (int j = 0; j < N; ++j) { s[j] = __expf(s[j] - mx); den += s[j]; }
             float o[DK];
 #pragma unroll
             for (int e = 0; e < DK; ++e) o[e] = 0.f;
+            const float rden = 1.0f / den;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                float p = s[j] / den;
+                float p = s[j] * rden;
                 if (attn0 != nullptr && l == 0 && g0 + g < batch)
                     attn0[(((size_t)(g0 + g) * H + hd) * N + i) * N + j] = p;
                 if constexpr (DROP) if (g0 + g < batch) p = drop_apply(p, KL[(size_t)row * dm.per_layer + hd * N + j], dm.keep_prob);   // transformer.py:19

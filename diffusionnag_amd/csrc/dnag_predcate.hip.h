@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
                         accv = fmaf(o[e], v4.x, accv); accv = fmaf(o[e + 1], v4.y, accv);
                         accv = fmaf(o[e + 2], v4.z, accv); accv = fmaf(o[e + 3], v4.w, accv);
                     }
-                    acc = acc / sqrtf((float)DK);
+                    acc = acc * (1.0f / sqrtf((float)DK));    // constant-folded reciprocal
                     if (maskb[(g * N + n) * N + j] == 0.f) acc = -1e9f;
                     s[j] = acc;
                     dp[j] = accv;
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
                 }
                 float den = 0.f;
 #pragma unroll
-                for (int j = 0; j < N; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+                for (int j = 0; j < N; ++j) { s[j] = __expf(s[j] - mx); den += s[j]; }
                 float c = 0.f;
 #pragma unroll
-                for (int j = 0; j < N; ++j) { s[j] = s[j] / den; c = fmaf(s[j], dp[j], c); }
+                for (int j = 0; j < N; ++j) { s[j] = s[j] * (1.0f / den); c = fmaf(s[j], dp[j], c); }
 #pragma unroll
                 for (int e = 0; e < DK; ++e) dq[e] = 0.f;
                 float *Pr = Pm + ((g * H + hd) * N + n) * N;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     // masked_fill (transformer.py:16) passes no gradient to a filled score
-                    const float ds = (maskb[(g * N + n) * N + j] == 0.f) ? 0.f : s[j] * (dp[j] - c) / sqrtf((float)DK);
+                    const float ds = (maskb[(g * N + n) * N + j] == 0.f) ? 0.f : s[j] * (dp[j] - c) * (1.0f / sqrtf((float)DK));
                     Pr[j] = s[j];
                     Sr[j] = ds;
                     const float *kp = qb + (g * N + j) * QS + D + hd * DK;

@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
                         accv = fmaf(o[e], v4.x, accv); accv = fmaf(o[e + 1], v4.y, accv);
                         accv = fmaf(o[e + 2], v4.z, accv); accv = fmaf(o[e + 3], v4.w, accv);
                     }
-                    acc = acc / sqrtf((float)DK);
+                    acc = acc * (1.0f / sqrtf((float)DK));    // constant-folded reciprocal
                     if (maskb[(g * N + n) * N + j] == 0.f) acc = -1e9f;
                     s[j] = acc;
                     dp[j] = accv;                   // d loss / d a[n][j]
@@ -767,13 +767,13 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
                 }
                 float den = 0.f;
 #pragma unroll
-                for (int j = 0; j < N; ++j) { s[j] = expf(s[j] - mx); den += s[j]; }
+                for (int j = 0; j < N; ++j) { s[j] = __expf(s[j] - mx); den += s[j]; }
                 const bool lv = g0 + g < batch;
                 const uint8_t *ka = (drop && lv) ? KL + (row0 + row) * PL + hd * N : nullptr;
                 float c = 0.f;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    s[j] = s[j] / den;
+                    s[j] = s[j] * (1.0f / den);
                     if (ka) dp[j] = drop_apply(dp[j], ka[j], kp);     // d loss / d P[n][j]
                     c = fmaf(s[j], dp[j], c);
                 }
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     // masked_fill (transformer.py:16) passes no gradient to a filled score
-                    const float ds = (maskb[(g * N + n) * N + j] == 0.f) ? 0.f : s[j] * (dp[j] - c) / sqrtf((float)DK);
+                    const float ds = (maskb[(g * N + n) * N + j] == 0.f) ? 0.f : s[j] * (dp[j] - c) * (1.0f / sqrtf((float)DK));
                     const float a = ka ? drop_apply(s[j], ka[j], kp) : s[j];
                     Pr[j] = a;
                     Sr[j] = ds;
