@@ -1,0 +1,41 @@
+"""Timing ablation of the sampling encoder / surrogate kernel: DNAG_ENC_SKIP / DNAG_PRED_SKIP bits switch phases off
+(results are then wrong; timing only).  Run on the GPU box: python tests/micro/enc_ablate.py"""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from diffusionnag_amd import mutils, synthetic, utils
+from diffusionnag_amd import cate, digcn_meta  # noqa
+from diffusionnag_amd.specs import CateDims, PredictorDims
+from tests.helpers import score_config, predictor_config
+dev = torch.device("cuda:0")
+B = 4096
+dims = CateDims()
+model = mutils.create_model(score_config(dims, dev)); model.load_state_dict(synthetic.cate_state_dict(dims, 0)); model.eval()
+X = torch.randn(B, dims.max_node, dims.n_vocab, device=dev); t = torch.full((1,), 500.0, device=dev)
+m = utils.aug_mask(utils.nb201_adj()).to(dev)
+clf = mutils.create_model(predictor_config(PredictorDims(), dev)); clf.load_state_dict(synthetic.predictor_state_dict(PredictorDims(), 1)); clf.eval()
+task = synthetic.synthetic_task(10, 20, 2).to(dev)
+clf.sample_state = True; clf.D_mu = None
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+base = None
+for name, skip in [("all", 0), ("-qkv", 1), ("-attn", 2), ("-o", 4), ("-ffn1", 8), ("-ffn2", 16), ("-outnorm", 64), ("-all linears", 29), ("only embed", 128), ("-everything", 95)]:
+    os.environ["DNAG_ENC_SKIP"] = str(skip)
+    us = timeit(lambda: model(X, t, m))
+    if base is None: base = us
+    print(f"score eval (encoder+GEMMs+exit) skip={skip:3d} {name:14s}: {us:8.1f} us  (delta {base - us:6.1f})", flush=True)
+os.environ["DNAG_ENC_SKIP"] = "0"
+base = None
+for skip in [0, 1, 2, 4, 8, 16, 32, 64, 128]:
+    os.environ["DNAG_PRED_SKIP"] = str(skip)
+    us = timeit(lambda: clf.input_grad(X, t, m, task=task))
+    if base is None: base = us
+    print(f"surrogate skip={skip:3d}: {us:8.1f} us (delta {base - us:6.1f})", flush=True)
