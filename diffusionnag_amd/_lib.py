@@ -23,7 +23,7 @@ SCORE_VP, SCORE_VE = range(2)
 
 # every symbol include/dnag.h declares (tests check that the built library exports them all)
 EXPORTS = (
-    "dnag_abi_version", "dnag_last_error",
+    "dnag_abi_version", "dnag_last_error", "dnag_pc_args_bytes", "dnag_train_args_bytes", "dnag_ofa_validity",
     "dnag_cate_state_floats", "dnag_cate_table_floats", "dnag_cate_packed_floats", "dnag_cate_pack",
     "dnag_pred_state_floats", "dnag_pred_table_floats", "dnag_pred_packed_floats", "dnag_pred_pack",
     "dnag_predcate_state_floats", "dnag_predcate_table_floats", "dnag_predcate_packed_floats", "dnag_predcate_pack",
@@ -71,6 +71,8 @@ class PcArgsC(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
         ("cscale_steps", _fp), ("guide_steps", C.c_void_p), ("weight_ratio", C.c_int32), ("weight_ratio_p", C.c_float),
         ("prod_w", C.c_int32),
+        ("chain_x", _fp), ("chain_steps", C.c_int32), ("chain_keep", C.c_int32), ("chain_n", C.c_int32),
+        ("chain_denoise", C.c_int32),
     ]
 
 
@@ -151,6 +153,13 @@ def load() -> C.CDLL:
     lib.dnag_cate_dsm_step.argtypes = [C.POINTER(TrainArgsC)]
     if lib.dnag_abi_version() != 1:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.dnag_abi_version()} != 1; rebuild the library")
+    lib.dnag_ofa_validity.restype = i32
+    lib.dnag_ofa_validity.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.dnag_pc_args_bytes.restype = sz
+    lib.dnag_train_args_bytes.restype = sz
+    if lib.dnag_pc_args_bytes() != C.sizeof(PcArgsC) or lib.dnag_train_args_bytes() != C.sizeof(TrainArgsC):
+        raise ImportError(f"{LIB_PATH}: argument structs ({lib.dnag_pc_args_bytes()}, {lib.dnag_train_args_bytes()} bytes) do not "
+                          f"match this binding ({C.sizeof(PcArgsC)}, {C.sizeof(TrainArgsC)}); rebuild the library")
     _lib = lib
     return lib
 

@@ -74,3 +74,61 @@ __global__ __launch_bounds__(1024) void nb201_count_kernel(const int32_t *__rest
 __global__ void fill_i32_kernel(int32_t *p, size_t n, int32_t v) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = v;
 }
+
+// ---------------------------------------------------------------------------------------------
+// MobileNetV3 / OFA search space: 5 stages x 4 layer slots = 20 nodes, 9 (kernel, expand) types; a row without a 1 is a
+// skipped layer.  Restates (reference MobileNetV3/): utils.py:244-262 (quantize: x >= 0.5),
+// analysis/arch_functions.py:374-380 (check_multiple_nodes), :386-392 (layers 1 and 2 of every stage must exist),
+// :394-402 (layer 4 needs layer 3), :413-429 (is_valid_OFA_x and its error codes).
+// One thread per graph.  status: -1 valid, 1 MULIPLE_NODES, 2 INVALID_1OR2_LAYERS, 3 INVALID_3AND4_LAYERS.
+// types [batch][20]: the row's type 0..8 (first 1 of the row), -1 for an empty row -- what
+// get_string_from_onehot_x (:135-144) needs; written for every graph.
+// ---------------------------------------------------------------------------------------------
+#define OFA_N 20
+#define OFA_V 9
+__global__ __launch_bounds__(256) void ofa_validity_kernel(const float *__restrict__ x, int batch, int32_t *__restrict__ status,
+                                                           int8_t *__restrict__ types) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= batch) return;
+    const float *xb = x + (size_t)b * OFA_N * OFA_V;
+    uint32_t empty = 0, multi = 0;            // bit n: row n has no 1 / more than one 1
+    for (int n = 0; n < OFA_N; ++n) {
+        int cnt = 0, arg = -1;
+#pragma unroll
+        for (int v = 0; v < OFA_V; ++v) {
+            const bool one = xb[n * OFA_V + v] >= 0.5f;
+            if (one && cnt == 0) arg = v;
+            cnt += one ? 1 : 0;
+        }
+        if (cnt == 0) empty |= 1u << n;
+        if (cnt > 1) multi |= 1u << n;
+        types[(size_t)b * OFA_N + n] = (int8_t)arg;
+    }
+    int st = -1;
+    if (multi) st = 1;
+    else {
+        const uint32_t first_second = 0x33333u;       // rows 0,1, 4,5, 8,9, 12,13, 16,17
+        const uint32_t third = 0x44444u;              // rows 2, 6, 10, 14, 18
+        if (empty & first_second) st = 2;
+        else if (((empty & third) << 1) & ~empty) st = 3;     // third empty, fourth not
+    }
+    status[b] = st;
+}
+
+// counts[0..3] = graphs with status -1, 1, 2, 3.  One block.
+__global__ __launch_bounds__(1024) void ofa_count_kernel(const int32_t *__restrict__ status, int batch, int32_t *__restrict__ counts) {
+    __shared__ int sv[4][1024];
+    int c[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < batch; i += 1024) {
+        const int s = status[i];
+        c[s < 0 ? 0 : s] += 1;
+    }
+    for (int k = 0; k < 4; ++k) sv[k][threadIdx.x] = c[k];
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int k = 0; k < 4; ++k) sv[k][threadIdx.x] += sv[k][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) counts[threadIdx.x] = sv[threadIdx.x][0];
+}

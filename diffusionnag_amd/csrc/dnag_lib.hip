@@ -39,6 +39,8 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" int dnag_abi_version(void) { return 1; }
+extern "C" size_t dnag_pc_args_bytes(void) { return sizeof(dnag_pc_args); }
+extern "C" size_t dnag_train_args_bytes(void) { return sizeof(dnag_train_args); }
 extern "C" const char *dnag_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------------
@@ -774,6 +776,10 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
         return fail(DNAG_E_ARG, "weight_ratio=%d weight_ratio_p=%g", p->weight_ratio, p->weight_ratio_p);
     if ((p->noise_corr == nullptr) != (p->noise_pred == nullptr) && p->corrector)
         return fail(DNAG_E_ARG, "noise_corr and noise_pred must both be given (tape mode) or both NULL (Philox)");
+    const int chain_n = p->chain_n > 0 ? p->chain_n : p->n_steps;
+    if (p->chain_x && (p->chain_steps < 1 || p->chain_steps > chain_n || p->chain_keep < 1 || p->chain_keep > p->batch || p->n_steps > chain_n))
+        return fail(DNAG_E_ARG, "chain_steps=%d chain_keep=%d chain_n=%d (need 1 <= steps <= chain_n, 1 <= keep <= batch, n_steps <= chain_n)",
+                    p->chain_steps, p->chain_keep, chain_n);
     const dnag_cate_dims &cd = *p->cate_dims;
     const CateLayout lay = cate_layout(cd);
     const WsLayout w = ws_layout(cd, p->pred_dims, p->batch, p->n_steps, p->predcate_dims);
@@ -861,6 +867,16 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
                 const int grid = (int)((nelem + 255) / 256 < 2048 ? (nelem + 255) / 256 : 2048);
                 hipLaunchKernelGGL(corrector_update_kernel, dim3(grid), dim3(256), 0, st, c);
                 LAUNCH_CHECK();
+            }
+        }
+        if (p->chain_x) {   // MobileNetV3/sampling.py:1030-1034; only the last step of a slot survives there
+            const long long cs = p->chain_steps;
+            const long long slot = (i * cs) / chain_n;
+            if (i == S - 1 || ((i + 1) * cs) / chain_n != slot) {
+                // a None predictor returns (x, x): x_mean is x then (sampling.py:216-224)
+                const float *src = (p->chain_denoise && p->predictor != DNAG_PREDICTOR_NONE) ? x_mean : x;
+                const size_t n = (size_t)p->chain_keep * cd.max_node * cd.n_vocab;
+                HIP_TRY(hipMemcpyAsync(p->chain_x + (size_t)(cs - 1 - slot) * n, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
         }
     }
@@ -1164,6 +1180,21 @@ extern "C" int dnag_nb201_validity(const float *x, int batch, int32_t *status, i
     }
     if (counts) {
         hipLaunchKernelGGL(nb201_count_kernel, dim3(1), dim3(1024), 0, st, status, batch, first_seen, counts);
+        LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int dnag_ofa_validity(const float *x, int batch, int32_t *status, int8_t *types, int32_t *counts, void *stream) {
+    if (batch > 0 && (!x || !status || !types)) return fail(DNAG_E_ARG, "NULL pointer");
+    if (batch < 0) return fail(DNAG_E_ARG, "batch=%d", batch);
+    hipStream_t st = (hipStream_t)stream;
+    if (batch > 0) {
+        hipLaunchKernelGGL(ofa_validity_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, x, batch, status, types);
+        LAUNCH_CHECK();
+    }
+    if (counts) {
+        hipLaunchKernelGGL(ofa_count_kernel, dim3(1), dim3(1024), 0, st, status, batch, counts);
         LAUNCH_CHECK();
     }
     return 0;

@@ -160,6 +160,7 @@ class _PCSampler:
         self.seed = 0
         self.stream_offset = 0
         self.weighting: Optional[dict] = None
+        self.last_chain: Optional[torch.Tensor] = None
         self._ws = Workspace()
         self._calls = 0
 
@@ -190,7 +191,7 @@ class _PCSampler:
         return cs, on, mode, float(wo.get("p", 1)), int(bool(wo.get("prod_w")))
 
     # ---------------------------------------------------------------------------------------------
-    def _run(self, score_model: CATE, mask, classifier=None, classifier_scale=None, task=None, labels='max'):
+    def _run(self, score_model: CATE, mask, classifier=None, classifier_scale=None, task=None, labels='max', chain=None):
         lib = _lib.load()
         dev = self.device
         if dev.type != "cuda":
@@ -283,6 +284,14 @@ class _PCSampler:
         x_last = torch.empty_like(out)
         x_mean = torch.empty_like(out)
         args.x_out, args.x_last, args.x_mean_last = _lib.ptr(out), _lib.ptr(x_last), _lib.ptr(x_mean)
+        chain_x = None
+        if chain is not None:                                        # MobileNetV3/sampling.py:980-988
+            ncs = chain.get("number_chain_steps") or self.sde.N
+            kc = chain.get("keep_chain") or B
+            assert ncs <= self.sde.N
+            chain_x = torch.zeros(ncs, kc, N, V, dtype=torch.float32, device=dev)
+            args.chain_x, args.chain_steps, args.chain_keep = _lib.ptr(chain_x), int(ncs), int(kc)
+            args.chain_n, args.chain_denoise = int(self.sde.N), int(bool(self.denoise))
         rec = None
         if self.record:
             names = ["rec_score_c", "rec_total_c", "rec_x_corr", "rec_score_p", "rec_total_p", "rec_x_mean", "rec_x_pred"]
@@ -306,6 +315,13 @@ class _PCSampler:
             classifier.sample_state = False                          # sampling.py:576
         self.last_record = rec
         del keep
+        # the reference keeps the chain on the host (torch.zeros on the default device, filled from the GPU)
+        self.last_chain = None
+        if chain_x is not None:
+            ncs = chain_x.shape[0]
+            hit = sorted({ncs - 1 - (i * ncs) // self.sde.N for i in range(S)})    # slots a truncated run never reaches stay 0
+            chain_x[hit] = self.inverse_scaler(chain_x[hit])
+            self.last_chain = chain_x.cpu()
         kind = getattr(self.inverse_scaler, "dnag_kind", None)
         if self.denoise and kind == "centered":
             return out                                               # (x_mean + 1) / 2 from the exit kernel
@@ -332,11 +348,21 @@ class _PCConditional(_PCSampler):
         # the reference opens the feature blob here (sampling.py:490-493); it is opened on first use instead
         self.test_dataset = MetaTestDataset(data_path=DATA_PATH, data_name=data_name, num_sample=num_sample)
 
-    def __call__(self, score_model, mask, classifier, classifier_scale=None, task=None):
-        """Reference ``pc_conditional_sampler`` (``sampling.py:534-577``): returns the samples."""
+    def __call__(self, score_model, mask, classifier, classifier_scale=None, task=None, eval_chain=None,
+                 keep_chain=None, number_chain_steps=None, sample_bs=None):
+        """Reference ``pc_conditional_sampler`` (``sampling.py:534-577``): returns the samples.
+
+        Called with ``eval_chain`` (True or False), it answers like the MobileNetV3 tree's sampler
+        (``MobileNetV3/sampling.py:965-1037``): ``(samples, sde.N * (n_steps + 1), chain_x, norms)`` with ``chain_x``
+        ``[number_chain_steps, keep_chain, N, V]`` on the host (None unless ``eval_chain``); ``norms`` stands for that
+        sampler's four per-step gradient-norm lists, a logging aid that is not recorded here (four empty lists)."""
         if task is None:
             task = self.test_dataset[0]
-        return self._run(score_model, mask, classifier, classifier_scale, task, self.labels)
+        chain = dict(number_chain_steps=number_chain_steps, keep_chain=keep_chain) if eval_chain else None
+        x = self._run(score_model, mask, classifier, classifier_scale, task, self.labels, chain=chain)
+        if eval_chain is None:
+            return x
+        return x, self.sde.N * (self.n_steps + 1), self.last_chain, ([], [], [], [])
 
 
 def get_pc_sampler_nas(sde, shape, predictor, corrector, inverse_scaler, snr, n_steps=1, probability_flow=False,

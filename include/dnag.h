@@ -210,9 +210,24 @@ typedef struct dnag_pc_args {
     int32_t weight_ratio;
     float weight_ratio_p;
     int32_t prod_w;
+    /* Chain recording of the MobileNetV3 sampler (reference MobileNetV3/sampling.py:980-988, :1030-1034), NULL: off.
+     * After PC step i the first chain_keep graphs of (chain_denoise ? x_mean : x) -- raw, the caller applies its
+     * inverse scaler -- are copied to slot chain_steps - 1 - (i * chain_steps) / chain_n of chain_x
+     * [chain_steps][chain_keep][N][V] (device); later steps overwrite earlier ones of the same slot, as in the
+     * reference, so only the last step of every slot is copied.  chain_n = sde.N (0: n_steps); slots no step maps to
+     * (a truncated run) are left untouched: pass a zeroed buffer. */
+    float *chain_x;
+    int32_t chain_steps;
+    int32_t chain_keep;
+    int32_t chain_n;
+    int32_t chain_denoise;
 } dnag_pc_args;
 
 int dnag_pc_sample(const dnag_pc_args *args);
+/* sizeof(dnag_pc_args) / sizeof(dnag_train_args) as this library was built: a binding checks its own struct against
+ * them before the first call (no counterpart in the reference: its boundary is Python objects). */
+size_t dnag_pc_args_bytes(void);
+size_t dnag_train_args_bytes(void);
 
 /* ---- DSM training step (BASELINE config 3) --------------------------------------------------------
  * Replaces get_sde_loss_fn_nas(...).loss_fn (losses.py:127-166, likelihood_weighting=False) followed by
@@ -276,6 +291,14 @@ int    dnag_cate_dsm_step(const dnag_train_args *args);
 int dnag_nb201_seen_reset(int32_t *first_seen, void *stream);
 int dnag_nb201_validity(const float *x, int batch, int32_t *status, int32_t *code, int32_t *first_seen,
                         int32_t index_base, int32_t *counts, void *stream);
+
+/* Exit of a MobileNetV3 / OFA sampling round: threshold (reference MobileNetV3/utils.py:254-255) and the validity
+ * rules of is_valid_OFA_x (MobileNetV3/analysis/arch_functions.py:374-429) for x [batch][20][9] on the device.
+ *   status [batch]      -1 valid | 1 MULIPLE_NODES | 2 INVALID_1OR2_LAYERS | 3 INVALID_3AND4_LAYERS
+ *   types  [batch][20]  type 0..8 of every layer slot (first 1 of its row), -1 for a skipped layer: the input of
+ *                       get_string_from_onehot_x (:135-144); written for every graph
+ *   counts [4] (may be NULL)  graphs with status -1, 1, 2, 3 */
+int dnag_ofa_validity(const float *x, int batch, int32_t *status, int8_t *types, int32_t *counts, void *stream);
 
 /* ---- exit: threshold (utils.py:244-262) --------------------------------------------------------
  * q[i] = x[i] >= 0.5 ? 1 : 0, n elements, device pointers. */

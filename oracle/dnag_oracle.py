@@ -428,8 +428,13 @@ def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3,
               n_steps: Optional[int] = None, pred_sd: Optional[SD] = None, D_mu: Optional[Tensor] = None,
               classifier_scale: float = 0.0, labels: str = "max", record: Optional[list] = None,
               model_kw: Optional[dict] = None, predictor: str = "reverse_diffusion", corrector: str = "langevin",
-              weighting: Optional[dict] = None) -> Tensor:
+              weighting: Optional[dict] = None, chain: Optional[dict] = None) -> Tensor:
     """Predictor-corrector loop with injected noise (sampling.py:424-445 / :534-577).
+
+    ``chain`` = {'number_chain_steps': n, 'keep_chain': k, 'denoise': bool} restates the MobileNetV3 sampler's chain
+    recording (MobileNetV3/sampling.py:980-988, :1030-1034): after PC step i the first k graphs of
+    ``inverse_scaler(x_mean if denoise else x)`` go to slot ``n - 1 - (i * n) // sde.N`` of a zero tensor [n, k, N, V],
+    which is stored in ``chain['chain_x']`` (PARITY UNPINNED like the weighting options: same file).
 
     ``weighting`` (None: the NAS-Bench-201 tree's ``score + classifier_scale * grad``) restates the guidance weighting
     options that only the MobileNetV3 tree's sampler has (MobileNetV3/sampling.py:858-910, :924-957): keys
@@ -479,6 +484,11 @@ def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3,
         return s + w * cg, s, cg
 
     x_mean = x
+    if chain is not None:
+        ncs = chain.get('number_chain_steps') or sde.N                          # MBV3 :982-983
+        keep = chain.get('keep_chain') or B                                     # :984-985
+        assert ncs <= sde.N                                                     # :986
+        chain['chain_x'] = torch.zeros(ncs, keep, *x.shape[1:])                 # :987-988
     with torch.no_grad():
         for i in range(S):
             vec_t = torch.ones(B) * ts[i]                                       # :442
@@ -523,6 +533,9 @@ def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3,
             if rec is not None:
                 rec.update(score_p=s2, cgrad_p=cg2, total_p=grad2, x_mean=x_mean.clone(), x_pred=x.clone())
                 record.append(rec)
+            if chain is not None:                                               # MBV3 :1030-1034
+                write_index = ncs - 1 - int((i * ncs) // sde.N)
+                chain['chain_x'][write_index] = inverse_scaler(x_mean if chain.get('denoise', True) else x)[:keep]
     return inverse_scaler(x_mean)
 
 
@@ -569,4 +582,53 @@ def compute_validity(generated, ops=NB201_OPS):
         ok, err = is_valid_nas201_x(x, ops.index('input'), ops.index('output'))
         errs.append(err)
         strs.append(nb201_code_to_string(nb201_arch_code(x), ops) if ok else None)
+    return errs, strs
+
+
+# ----------------------------------------------------------------------------------------------
+# Exit of a MobileNetV3 / OFA sampling round (MobileNetV3/analysis/arch_functions.py:8-24, :135-163, :374-429).
+# PARITY UNPINNED: that module imports wandb and igraph, which are not installed here, so it cannot be imported to
+# capture goldens; this restatement follows its text and is checked on hand-derived known answers
+# (tests/test_oracle_golden.py) and against the kernel.
+# ----------------------------------------------------------------------------------------------
+OFA_NUM_STAGE, OFA_MAX_LAYER_PER_STAGE = 5, 4                                      # :11-12
+OFA_OPS2STR = {0: '3-3', 1: '3-4', 2: '3-6', 3: '5-3', 4: '5-4', 5: '5-6', 6: '7-3', 7: '7-4', 8: '7-6'}   # :20-24
+
+
+def is_valid_ofa_x(x):
+    """is_valid_OFA_x (:413-429): (ok, error code) for a quantised [20, 9] array."""
+    x = np.asarray(x)
+    assert x.ndim == 2
+    for row in x:                                                                  # check_multiple_nodes :374-380
+        if int(np.sum(row)) > 1:
+            return False, 1
+    for layer in [0, 1, 4, 5, 8, 9, 12, 13, 16, 17]:                               # check_none_in_1_and_2_layers :386-392
+        if int(np.sum(x[layer])) == 0:
+            return False, 2
+    for layer in [2, 6, 10, 14, 18]:                                               # check_none_in_3_and_4_layers :394-402
+        if int(np.sum(x[layer])) == 0 and int(np.sum(x[layer + 1])) != 0:
+            return False, 3
+    return True, -1
+
+
+def ofa_string_from_onehot_x(x):
+    """get_string_from_onehot_x (:135-144): '<stage depth>-<kernel>-<expand>' per layer slot, '0-0-0' for a skipped one."""
+    x = np.asarray(x)
+    ds = x.reshape(OFA_NUM_STAGE, -1).sum(axis=1)
+    parts = []
+    for i, row in enumerate(x):
+        if row.sum() == 0:
+            parts.append('0-0-0')
+        else:
+            parts.append(f'{int(ds[i // OFA_MAX_LAYER_PER_STAGE])}-' + OFA_OPS2STR[int(np.nonzero(row)[0][0])])
+    return '_'.join(parts)
+
+
+def compute_validity_ofa(generated):
+    """BasicArchMetricsMetaOFA.compute_validity (:146-163): (error code per sample, string or None per sample)."""
+    errs, strs = [], []
+    for x in generated:
+        ok, err = is_valid_ofa_x(x)
+        errs.append(err)
+        strs.append(ofa_string_from_onehot_x(x) if ok else None)
     return errs, strs

@@ -44,3 +44,30 @@ def predictor_cate_config(d, device):
 
 def golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def ofa_sampler_like_outputs(B, seed):
+    """[B, 20, 9] floats in the sampler's output scale: mostly valid OFA encodings (stage depths 2..4, one type per
+    used layer slot) pushed off 0/1 by noise that never crosses the 0.5 threshold, plus every rule violation of
+    MobileNetV3/analysis/arch_functions.py:374-429 and some unstructured graphs."""
+    rs = np.random.RandomState(seed)
+    x = np.zeros((B, 20, 9), np.float32)
+    for b in range(B):
+        kind = rs.randint(0, 10)
+        for s in range(5):
+            d = rs.randint(2, 5)
+            for j in range(d):
+                x[b, 4 * s + j, rs.randint(9)] = 1.0
+        if kind == 0:
+            x[b, rs.randint(20), rs.randint(9)] = 1.0            # (maybe) a second type in one slot
+        elif kind == 1:
+            x[b, 4 * rs.randint(5) + rs.randint(2)] = 0.0        # a missing first / second layer
+        elif kind == 2:
+            s = rs.randint(5)
+            x[b, 4 * s + 2] = 0.0                                # third layer skipped ...
+            x[b, 4 * s + 3, rs.randint(9)] = 1.0                 # ... but a fourth one
+        elif kind == 3:
+            x[b] = rs.uniform(0, 1, size=(20, 9)) > 0.9
+    x = x + rs.uniform(-0.45, 0.45, size=x.shape).astype(np.float32)
+    x[0, 0, :] = [0.5, 0.1, 0.2, 0.3, 0.1, 0.0, 0.2, 0.4, 0.49]   # exactly 0.5 counts as 1 (>=)
+    return x.astype(np.float32)

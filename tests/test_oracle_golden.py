@@ -280,3 +280,35 @@ def test_validity_rules_and_strings(golden, name):
     valid = [s for s in strs if s is not None]
     assert len(valid) / len(strs) == float(g["validity"])
     assert len(set(valid)) == int(g["n_unique"])
+
+
+# ----------------------------------------------------------------------------------------------
+# OFA validity rules and strings: PARITY UNPINNED (the reference module imports wandb and igraph, not installed):
+# hand-derived known answers from the text of MobileNetV3/analysis/arch_functions.py:135-144, :374-429
+# ----------------------------------------------------------------------------------------------
+def _ofa_x(depths, types=None):
+    x = np.zeros((20, 9), np.float32)
+    for s, d in enumerate(depths):
+        for j in range(d):
+            x[4 * s + j, (types or {}).get(4 * s + j, 0)] = 1.0
+    return x
+
+
+def test_ofa_validity_known_answers():
+    ok = _ofa_x([2, 3, 4, 2, 3], {0: 8, 5: 4, 10: 2})
+    assert O.is_valid_ofa_x(ok) == (True, -1)
+    s = O.ofa_string_from_onehot_x(ok).split('_')
+    assert len(s) == 20
+    assert s[0] == '2-7-6' and s[1] == '2-3-3' and s[2] == '0-0-0' and s[3] == '0-0-0'      # stage 0: depth 2, type 8 = '7-6'
+    assert s[4] == '3-3-3' and s[5] == '3-5-4' and s[6] == '3-3-3' and s[7] == '0-0-0'
+    assert s[8] == '4-3-3' and s[10] == '4-3-6' and s[11] == '4-3-3'
+    multi = ok.copy(); multi[9, 3] = 1.0                                                     # slot 9 already has type 0
+    assert O.is_valid_ofa_x(multi) == (False, 1)
+    no2 = ok.copy(); no2[13] = 0.0                                                           # second layer of stage 3
+    assert O.is_valid_ofa_x(no2) == (False, 2)
+    gap = ok.copy(); gap[2, 1] = 0.0; gap[3, 1] = 1.0                                        # stage 0: layer 4 without layer 3
+    assert O.is_valid_ofa_x(gap) == (False, 3)
+    both = multi.copy(); both[13] = 0.0                                                      # the first failing rule wins
+    assert O.is_valid_ofa_x(both) == (False, 1)
+    errs, strs = O.compute_validity_ofa([ok, multi, no2, gap])
+    assert errs == [-1, 1, 2, 3] and strs[1:] == [None, None, None] and strs[0] == '_'.join(s)
