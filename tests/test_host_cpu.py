@@ -346,11 +346,15 @@ print("rank", rank, "ok")
 
 
 def test_gather_world_size_2_gloo(tmp_path):
+    import socket
+    with socket.socket() as sk:          # a free port: a fixed one can still be in TIME_WAIT from the previous run
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     env = dict(os.environ, DNAG_REPO=REPO, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                        env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
