@@ -341,7 +341,7 @@ x = (torch.arange(start, start + count, dtype=torch.float32)[:, None, None] + to
 full = D.gather_samples(x, total)
 assert full.shape == (total, 8, 7), full.shape
 assert torch.equal(full[:, 0, 0], torch.arange(total, dtype=torch.float32)), full[:, 0, 0]
-print("rank", rank, "ok")
+sys.stdout.write(f"rank {rank} ok\n"); sys.stdout.flush()      # one write: two ranks share the pipe
 """
 
 
