@@ -285,6 +285,14 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
+#ifdef DNAG_ENC_STAMPS
+    long long ts_[96];
+    int nts_ = 0;
+#define ENC_STAMP() do { if (nts_ < 96) ts_[nts_++] = clock64(); } while (0)
+    ENC_STAMP();
+#else
+#define ENC_STAMP()
+#endif
 
     // weight tiles kept in registers across phases: bP/bQ (K = 64) and bR (K = DFF)
     float bP[D / 2], bQ[D / 2], bR[DFF / 2];
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         maskb[i] = mask[(size_t)(mstride ? gg : 0) * N * N + ij];
     }
     __syncthreads();
+    ENC_STAMP();
     // ---- embedding: (x We^T + be) * sqrt(d) + PE + temb   (transformer.py:230, cate.py:149-159) ----
     {
         const float *We = P + lay.emb_w, *be = P + lay.emb_b, *pe = P + lay.pe;
@@ -341,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         }
     }
     __syncthreads();
+    ENC_STAMP();
     if (dbg_skip & 128) return;
     // row `lr` of this workgroup is a real graph row (SAVE stores skip the padding)
     auto live = [&](int lr) { return lr < R && g0 + lr / N < batch; };
@@ -369,6 +379,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         constexpr bool PF_ATT = N <= 8;   // larger graphs need the registers for the attention rows
         if (PF_ATT && ft_o >= 0) load_w64(LP + wofs + lay.l_wo, ft_o, bP);   // lands while attention runs
         __syncthreads();
+        ENC_STAMP();
         // ---- attention per (graph, head, query) ---------------------------------------------------
         if (!(dbg_skip & 2))
         for (int it = tid; it < G * H * N; it += 256) {
@@ -420,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         }
         if (!PF_ATT && ft_o >= 0) load_w64(LP + wofs + lay.l_wo, ft_o, bP);
         __syncthreads();
+        ENC_STAMP();
         // ---- h += attn Wo^T + bo ------------------------------------------------------------------
         if (!(dbg_skip & 4)) {
             const float *W = LP + wofs + lay.l_wo, *bias = LP + lay.l_bo;
@@ -447,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
             load_frag<DFF>(w, ft_f2, bR);
         }
         __syncthreads();
+        ENC_STAMP();
         // ---- hidden = relu(LN2(h) W1'^T + b1') -----------------------------------------------------
         if (!(dbg_skip & 8)) {
             const float *W = LP + wofs + lay.l_w1, *bias = LP + lay.l_b1;
@@ -467,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         }
         if (l + 1 < L && ft_qkv >= 0) load_w64(LP + wofs + lay.layer_stride + lay.l_wqkv, ft_qkv, bP);   // next layer's first tile
         __syncthreads();
+        ENC_STAMP();
         // ---- h += hidden W2^T + b2 ----------------------------------------------------------------
         if (!(dbg_skip & 16)) {
             const float *W = LP + wofs + lay.l_w2, *bias = LP + lay.l_b2;
@@ -489,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                 });
         }
         __syncthreads();
+        ENC_STAMP();
         // ---- layer output norm (transformer.py:177) -> concat slice: 16 lanes per row, DPP statistics ----
         if (!(dbg_skip & 64)) {
             const float *og = LP + lay.l_ong, *ob = LP + lay.l_onb;
@@ -527,6 +542,10 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                 }
             }
         }
+        ENC_STAMP();
         // no barrier needed: the next phase only reads hbuf and writes qkv
     }
+#ifdef DNAG_ENC_STAMPS
+    if (blockIdx.x == 5 && tid == 0) for (int i = 1; i < nts_; ++i) printf("enc %d %lld\n", i, ts_[i] - ts_[i - 1]);
+#endif
 }
