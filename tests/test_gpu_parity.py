@@ -135,6 +135,39 @@ def test_predictor_hs512_and_ragged_batch_matches_oracle():
     close(gr, ref_g, 1e-5, "grad")
 
 
+@pytest.mark.parametrize("xscale,mask_kind", [(1e3, "random"), (1e-4, "random"), (1.0, "zeros"), (1.0, "ones"), (30.0, "column")])
+def test_predictor_operand_scales_hold_for_extreme_inputs(xscale, mask_kind):
+    """The surrogate's GEMM operands are split into fp16 hi/lo with a power-of-two scale that is a BOUND derived from
+    the mixing's input (row-normalised adjacency; largest column sum for the transposed products).  Inputs far from
+    the sampler's range and adjacencies that make the bound loose or tight ('column': every node points at node 0, the
+    largest possible column sum) must neither overflow nor lose accuracy."""
+    from oracle import dnag_oracle as O
+    sdp = synthetic.predictor_state_dict(PredictorDims(), seed=5)
+    clf = make_pred(5)
+    task = synthetic.synthetic_task(10, 20, seed=3)
+    D_mu = O.set_encode(sdp, task)
+    rs = np.random.RandomState(12)
+    B = 21
+    X = torch.from_numpy((rs.standard_normal((B, 8, 7)) * xscale).astype(np.float32))
+    t = torch.from_numpy(rs.uniform(1e-3, 1, B).astype(np.float32))
+    if mask_kind == "random":
+        masks = torch.from_numpy((rs.uniform(0, 1, (B, 8, 8)) < 0.5).astype(np.float32))
+    elif mask_kind == "zeros":
+        masks = torch.zeros(B, 8, 8)
+    elif mask_kind == "ones":
+        masks = torch.ones(B, 8, 8)
+    else:
+        masks = torch.zeros(B, 8, 8)
+        masks[:, :, 0] = 1.0
+    ref_y = O.predictor_forward(sdp, X, t * 999, masks, D_mu)
+    ref_g = O.classifier_grad(sdp, X, t, masks, D_mu)
+    y = clf(X.to(DEV), (t * 999).to(DEV), masks.to(DEV), task=task.to(DEV))
+    gr = clf.input_grad(X.to(DEV), (t * 999).to(DEV), masks.to(DEV), task=task.to(DEV))
+    assert torch.isfinite(y).all() and torch.isfinite(gr).all()
+    close(y, ref_y, 1e-5, "y")
+    close(gr, ref_g, 2e-5, "grad")
+
+
 # ------------------------------------------------------------------------------------------------
 # sampler trajectories against the reference's recorded runs (injected noise tape)
 # ------------------------------------------------------------------------------------------------
