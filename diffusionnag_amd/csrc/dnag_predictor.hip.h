@@ -318,9 +318,6 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         }
         return sa;
     };
-    auto load_b144 = [&](const float *F, int nt, int, int, float (&b)[GH / 2]) {   // fragment-major, zero padded
-        load_frag<GH>(F, nt, b);
-    };
 
     // ---- layers 1 .. L-1 forward -----------------------------------------------------------------
     static_assert(PRED_NW == PRED_NT * MT, "one (column tile, row tile) pair per wave in the layer GEMMs");
