@@ -20,7 +20,10 @@ __global__ __launch_bounds__(512, 1) void mfma_only(float *out, int iters) {
 }
 
 int main() {
-    const int M = 32768, N = 1536, K = 1536;
+#ifndef BENCH_K
+#define BENCH_K 1536
+#endif
+    const int M = 32768, N = 1536, K = BENCH_K;
     float *A, *W, *bias, *C;
     hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&W, (size_t)N * K * 4); hipMalloc(&bias, N * 4); hipMalloc(&C, (size_t)M * N * 4);
     {   // random split-pair operands
@@ -36,7 +39,11 @@ int main() {
         hipMemset(bias, 0, N * 4);
     }
     typedef SplitGeom Ge;
+#ifdef BENCH_OUTSPLIT
+    auto kern = gemm_split_kernel<ACT_ELU, true, 0>;      // final.linears.0: split-pair output rows
+#else
     auto kern = gemm_split_kernel<ACT_ELU, false, 1>;
+#endif
     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = (M / Ge::BM) * (N / Ge::BN);
