@@ -241,7 +241,7 @@ def main():
             "metric": "guided arch samples/sec (full reverse SDE), " + ("OFA" if ofa else "NB201"), "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (head GEMMs: f16 hi/lo pairs, 22 significant bits, f32 accumulation)", "data": "synthetic",
+            "dtype": "f32 (matrix products on f16 hi/lo operand pairs, 22 significant bits, f32 accumulation)", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[3]: MobileNetV3/OFA 20-node graphs, guided sampling (MetaPredictorCATE gradient), "
                                     f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
                                     "snr 0.16, classifier_scale 1e3, chain mask, random-init weights (seeded), Philox noise on device")
