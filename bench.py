@@ -103,7 +103,7 @@ def cpu_baseline(seconds=12.0):
                       f"x1000 steps per trajectory"}
 
 
-def bench_train(a):
+def bench_train(a, emit=True):
     """BASELINE configs[2]: NAS-Bench-201 score-network DSM training step (loss + gradient of every parameter,
     dropout 0.1 with on-device Philox masks) at batch 1024 on one GPU.  A step = dnag_cate_dsm_step on resident
     inputs (the optimiser is the caller's, losses.py:22-36).  Algorithmic FLOPs: 3 x 63.36 MFLOP per graph
@@ -151,7 +151,9 @@ def bench_train(a):
             "graphs_per_s": B * steps / dt, "whole_step_tflops": flop * steps / dt / 1e12,
             "whole_step_frac_of_f32_mfma_peak": flop * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
             "loss": float(loss), "grads_finite": bool(torch.isfinite(grads).all())}
-    print(json.dumps(line), flush=True)
+    if emit:
+        print(json.dumps(line), flush=True)
+    return line
 
 
 def main():
@@ -159,7 +161,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--batch-per-gpu", type=int, default=None,
+                    help="graphs per GPU; default 4096 at --gpus 1 (BASELINE configs[1]) and 8192 at --gpus N > 1 "
+                         "(BASELINE configs[4]: 65 536 graphs as 8 shards of 8192, weak scaling)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the short OFA and training side measurements (N = 1 only)")
     ap.add_argument("--sde-steps", type=int, default=1000, help="PC steps per trajectory (1000 = the full reverse SDE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["nb201", "ofa", "train"], default="nb201",
@@ -167,8 +172,30 @@ def main():
                          "a side measurement that never replaces the headline line; train = configs[2] (DSM training step, "
                          "forward + backward, batch 1024), also a side measurement")
     a = ap.parse_args()
+    if a.batch_per_gpu is None:
+        a.batch_per_gpu = 4096 if a.gpus == 1 else 8192
     if a.workload == "train":
         return bench_train(a)
+    line = bench_sampling(a, a.workload, a.steps, a.warmup)
+    if line is not None and a.gpus == 1 and a.workload == "nb201" and not a.no_extra:
+        # side workloads, driver-timed with the headline (short runs; they never replace `value`)
+        ofa = bench_sampling(a, "ofa", 1, 1)
+        tr = bench_train(a, emit=False)
+        line["extra"] = {
+            "ofa_guided_samples_per_s": ofa["value"], "ofa_ms_per_step": ofa["ms_per_step"], "ofa_workload": ofa["config"]["workload"],
+            "ofa_whole_path_tflops": ofa["whole_path_tflops"],
+            "train_steps_per_s": tr["value"], "train_ms_per_step": tr["ms_per_step"], "train_workload": tr["config"]["workload"],
+            "train_whole_step_tflops": tr["whole_step_tflops"],
+        }
+    if line is not None:
+        print(json.dumps(line), flush=True)
+    if a.gpus > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+def bench_sampling(a, workload, steps, warmup):
+    """One sampling measurement; returns the JSON line on rank 0 (None elsewhere)."""
 
     rank, world, local = D.init_from_env()
     if world != a.gpus:
@@ -178,7 +205,7 @@ def main():
     B = a.batch_per_gpu
     total = B * world
 
-    ofa = a.workload == "ofa"
+    ofa = workload == "ofa"
     dims = OFA_DIMS if ofa else CateDims()
     N, V = dims.max_node, dims.n_vocab
     cfg = score_config(dev, dims)
@@ -213,13 +240,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         out = step()
     lib = _lib.load()
     _lib.check(lib.dnag_timing_begin(16, 2048), "dnag_timing_begin")
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         out = step()
     fence()
     dt = time.perf_counter() - t0
@@ -233,20 +260,23 @@ def main():
     dt = float(tmax.item())
     finite = bool(torch.isfinite(out).all())
 
+    line = None
     if rank == 0:
-        value = total * a.steps / dt
+        value = total * steps / dt
         achieved = flops.value / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
-        flop_per_sample = FLOP_PER_SAMPLE[a.workload]
+        flop_per_sample = FLOP_PER_SAMPLE[workload]
         line = {
             "metric": "guided arch samples/sec (full reverse SDE), " + ("OFA" if ofa else "NB201"), "value": value, "unit": "samples/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (matrix products on f16 hi/lo operand pairs, 22 significant bits, f32 accumulation)", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[3]: MobileNetV3/OFA 20-node graphs, guided sampling (MetaPredictorCATE gradient), "
                                     f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
                                     "snr 0.16, classifier_scale 1e3, chain mask, random-init weights (seeded), Philox noise on device")
                        if ofa else
-                                   ("BASELINE configs[1]: NAS-Bench-201 predictor-guided sampling (meta-predictor gradient), "
+                                   ((f"BASELINE configs[4]: NAS-Bench-201 predictor-guided sampling, {total} graphs sharded over {world} GPUs "
+                                     "(one Langevin batch per shard, RCCL all_gather of the samples), " if world > 1 else
+                                     "BASELINE configs[1]: NAS-Bench-201 predictor-guided sampling (meta-predictor gradient), ") +
                                     f"batch {B} per GPU, VPSDE beta 0.1-20 N={a.sde_steps}, reverse_diffusion + langevin, "
                                     "snr 0.16, classifier_scale 1e4, Floyd-closure mask, random-init weights (seeded), "
                                     "Philox noise on device"),
@@ -259,7 +289,7 @@ def main():
                          "mfma_issued_tflops": achieved * SPLIT_MFMA_PER_PRODUCT,
                          "mfma_issued_frac": achieved * SPLIT_MFMA_PER_PRODUCT / PEAK_F16_MFMA_TFLOPS,
                          "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES.get((a.workload, B)),
+                         "traffic": PMC_TRAFFIC_BYTES.get((workload, B)),
                          "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_traffic.json)",
                          "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value},
             "whole_path_tflops": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world,
@@ -269,10 +299,7 @@ def main():
         if not a.no_cpu_baseline and world == 1 and not ofa:
             line["cpu_baseline"] = cpu_baseline()
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-        torch.distributed.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

@@ -32,6 +32,7 @@ EXPORTS = (
     "dnag_quantize", "dnag_timing_begin", "dnag_timing_read", "dnag_timing_end",
     "dnag_nb201_seen_reset", "dnag_nb201_validity",
     "dnag_train_workspace_bytes", "dnag_dropout_mask_bytes", "dnag_dropout_fill", "dnag_cate_dsm_step",
+    "dnag_pred_forward_grad_noalloc",
 )
 
 
@@ -129,6 +130,8 @@ def load() -> C.CDLL:
     lib.dnag_cate_forward.argtypes = [C.POINTER(CateDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, sz, vp]
     lib.dnag_pred_forward_grad.restype = i32
     lib.dnag_pred_forward_grad.argtypes = [C.POINTER(PredDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, sz, vp]
+    lib.dnag_pred_forward_grad_noalloc.restype = i32
+    lib.dnag_pred_forward_grad_noalloc.argtypes = [C.POINTER(PredDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]
     lib.dnag_pc_sample.restype = i32
     lib.dnag_pc_sample.argtypes = [C.POINTER(PcArgsC)]
     lib.dnag_quantize.restype = i32

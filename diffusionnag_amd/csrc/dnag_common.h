@@ -27,9 +27,11 @@ struct CateLayout {
     size_t t1_w, t1_b, t2_w, t2_b;  // timeEmb1 [4d][d],[4d]; timeEmb2 [d][4d],[d]
     size_t layer0, layer_stride;
     size_t l_wqkv, l_bqkv, l_wo, l_bo, l_w1, l_b1, l_w2, l_b2, l_ong, l_onb;  // relative to a layer base
+    size_t l_sc;                  // per layer: 8 power-of-two scale factors of the split arithmetic (ENC_SC_*)
     size_t f0_w, f0_b, f1_w, f1_b, f2_w, f2_b;  // final.linears.{0,1,2}
     size_t pe, freq;              // [N][d], [d/2]
     size_t f0_s, f1_s;            // final.linears.{0,1} weights as split-pair fp16 rows (dnag_gemm16.hip.h), same sizes
+    size_t hsc;                   // 16 power-of-two scale factors of the head GEMMs (HEAD_SC_*)
     size_t delta16;               // layer0 + delta16: second copy of the layer blocks whose four matrices are fp16 hi/lo
                                   // fragments scaled by 256 (frag16_pack) for the encoder's split-arithmetic MFMAs
     size_t total;
@@ -60,6 +62,7 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
     y.l_b2 = l; l += d;
     y.l_ong = l; l += d;
     y.l_onb = l; l += d;
+    y.l_sc = l; l += 8;
     y.layer_stride = l;
     o += l * y.L;
     const size_t F = y.F, Hd = y.Hd;
@@ -73,10 +76,51 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
     y.freq = o; o += align4(d / 2);
     y.f0_s = o; o += Hd * F;
     y.f1_s = o; o += Hd * Hd;
+    y.hsc = o; o += 16;
     y.delta16 = o - y.layer0; o += y.layer_stride * y.L;
     y.total = o;
     return y;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Operand scales of the split arithmetic (dnag_gemm16.hip.h).  Every operand of a split MFMA product is multiplied
+// by a power of two before it is cut into fp16 hi + lo, and the product of the two scales is divided out of the fp32
+// accumulator (exactly).  The scales are chosen when the weights are packed, from the weights alone, so that no fp16
+// value can overflow whatever the input is:
+//   weights      sw = 2^k <= 256 with sw * max|w| <= SPLIT_LIMIT (256 for any matrix below |w| = 234);
+//   activations  sa = 2^k <= 16  with sa * bound   <= SPLIT_LIMIT, where `bound` is a worst-case magnitude derived
+//                from the producing layer's weights: 8 for a LayerNorm output without affine (|u_i| < sqrt(64)),
+//                8 max|gamma| + max|beta| with affine, max_c (8 ||W_c||_2 + |b_c|) for a linear on a LayerNorm output
+//                (Cauchy-Schwarz, ||u||_2 <= 8; attention outputs are convex combinations of such values),
+//                max_c (||W_c||_1 amax_in + |b_c|) for a linear on a bounded input; ReLU / ELU do not raise a bound >= 1.
+// Networks with ordinary weights get 256 / 16 everywhere (the only values round 1 used); a checkpoint with large
+// weights gets smaller powers of two and keeps its accuracy relative to the magnitudes involved.
+// ---------------------------------------------------------------------------------------------
+#define SPLIT_LIMIT 60000.0f
+static inline __host__ __device__ float split_pow2_scale(float bound, int kmax) {
+    int k = kmax;
+    if (bound > 0.f) {
+        int e;
+        frexpf(SPLIT_LIMIT / bound, &e);          // SPLIT_LIMIT / bound = m 2^e, m in [0.5, 1): 2^(e-1) <= ratio
+        k = e - 1 < kmax ? e - 1 : kmax;
+        if (k < -60) k = -60;
+    }
+    return ldexpf(1.0f, k);
+}
+static inline __host__ __device__ float weight_scale(float amax) { return split_pow2_scale(amax, 8); }
+static inline __host__ __device__ float act_scale(float bound) { return split_pow2_scale(bound, 4); }
+
+// per-layer table at l_sc
+#define ENC_SC_INV_QKV 0   // 1 / (16 sw_qkv)        A = LayerNorm output, scale 16
+#define ENC_SC_SA_O    1   // scale of the attention output (A operand of the output projection)
+#define ENC_SC_INV_O   2   // 1 / (sa_o sw_o)
+#define ENC_SC_INV_F1  3   // 1 / (16 sw_1)
+#define ENC_SC_SA_F2   4   // scale of the FFN hidden
+#define ENC_SC_INV_F2  5   // 1 / (sa_f2 sw_2)
+// head table at hsc
+#define HEAD_SC_SA_CONCAT 0   // scale of the concat rows the encoder writes
+#define HEAD_SC_F0        4   // final.linears.0: [0] 1 / (sa_in sw), [1] sa_out (the hidden it writes), [2], [3] unused
+#define HEAD_SC_F1        8   // final.linears.1 + .2 fused: [0] 1 / (sa_in sw), [1] sa of the ELU output, [2] sw of W3, [3] 1 / ([1] [2])
 
 // ---------------------------------------------------------------------------------------------
 // Fragment-major storage of a weight matrix W[rows][K] (rows K-contiguous) that is the B operand of
@@ -100,8 +144,9 @@ static inline void frag_pack(const float *W, size_t rows, size_t K, size_t ld, f
 
 // Split-arithmetic variant of frag_pack (dnag_gemm16.hip.h explains the arithmetic): the same fragment-major
 // addressing and byte size, but the 16-byte chunk q of a lane holds 8 fp16 values: chunks 2s and 2s+1 are the hi and
-// the lo halves of 256 * W[nt*32 + r][h*K/2 + 8s .. 8s+7], i.e. the B fragments of 32x32x16 step s.
-static inline void frag16_pack(const float *W, size_t rows, size_t K, size_t ld, float *out) {
+// the lo halves of sw * W[nt*32 + r][h*K/2 + 8s .. 8s+7], i.e. the B fragments of 32x32x16 step s (sw: weight_scale
+// of the matrix).
+static inline void frag16_pack(const float *W, size_t rows, size_t K, size_t ld, float *out, float sw = 256.0f) {
     const size_t ntiles = (rows + 31) / 32, KH = K / 2, NQ = K / 8;
     _Float16 *o = reinterpret_cast<_Float16 *>(out);
     for (size_t nt = 0; nt < ntiles; ++nt)
@@ -109,7 +154,7 @@ static inline void frag16_pack(const float *W, size_t rows, size_t K, size_t ld,
             for (size_t l = 0; l < 64; ++l)
                 for (size_t j = 0; j < 8; ++j) {
                     const size_t row = nt * 32 + (l & 31), k = (l >> 5) * KH + 8 * (q >> 1) + j;
-                    const float w = row < rows ? W[row * ld + k] * 256.0f : 0.f;
+                    const float w = row < rows ? W[row * ld + k] * sw : 0.f;
                     const _Float16 hi = (_Float16)w;
                     o[((nt * NQ + q) * 64 + l) * 8 + j] = (q & 1) ? (_Float16)(w - (float)hi) : hi;
                 }
@@ -133,6 +178,7 @@ struct PredLayout {
     size_t p0_at;                 // transposed arch part [lh][hs]
     size_t p2_w, p2_b;            // pred_fc.2 [hs], [1]
     size_t freq;                  // [g/2]
+    size_t wsc;                   // 1 / sw of the split-arithmetic matrices: [2 l + {0: W1_l, 1: W2_l}], [2 L]: fc1
     size_t delta16;               // P + delta16 + (offset of w1b .. fc1b): the same fragment-major matrices as fp16 hi/lo
                                   // fragments scaled by 256 (frag16_pack) for the split-arithmetic MFMAs
     size_t total;
@@ -165,6 +211,7 @@ static inline __host__ __device__ PredLayout pred_layout(const dnag_pred_dims &c
     y.p2_w = o; o += align4(hs);
     y.p2_b = o; o += 4;
     y.freq = o; o += align4(g / 2);
+    y.wsc = o; o += align4(2 * DNAG_MAX_GCN + 1);
     y.delta16 = o - y.w1b[0];
     o += (y.fc1b + frag_floats(g, lh)) - y.w1b[0];
     y.total = o;

@@ -7,6 +7,10 @@
 #pragma once
 #include "dnag_common.h"
 
+#ifndef DNAG_ENC_SKIP
+#define DNAG_ENC_SKIP 0     // debug builds only (-DDNAG_ENC_SKIP=<mask>): phases switched off for timing ablations (wrong results)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // Tile jobs: out[32 x 32] = A[32 x K] * W[32 x K]^T on v_mfma_f32_32x32x2_f32.
 //   A lives in LDS (row stride `as` floats, as % 64 == 4 or 20 keeps ds_read_b128 conflict free),
@@ -19,7 +23,8 @@
 // hi/lo of 256 W); every A value is scaled by the power of two `sa`, split, and three v_mfma_f32_32x32x16_f16 per
 // 8 k values replace eight v_mfma_f32_32x32x2_f32; the accumulator is scaled back before the epilogue.
 template <int K, int MT, int NW, bool F16 = false, typename BLoad, typename AXf, typename Epi>
-__device__ __forceinline__ void run_jobs(int ntiles, const float *A, int as, BLoad bload, AXf axf, Epi epi, float sa = 16.0f) {
+__device__ __forceinline__ void run_jobs(int ntiles, const float *A, int as, BLoad bload, AXf axf, Epi epi, float sa = 16.0f,
+                                         float winv = 1.0f / 256.0f) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -61,7 +66,7 @@ __device__ __forceinline__ void run_jobs(int ntiles, const float *A, int as, BLo
                 acc = mfma16(ahi, blo, acc);
                 acc = mfma16(alo, bhi, acc);
             }
-            const float inv = 1.0f / (sa * 256.0f);
+            const float inv = winv / sa;          // sa, 1 / winv: the power-of-two scales of A and of the weight fragments
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] *= inv;
         } else {
@@ -145,11 +150,13 @@ struct JobSplit {
     __device__ static __forceinline__ int first_tile(int wave) { return wave * per < njobs ? (wave * per) / MT : -1; }
 };
 
-// F16: split-arithmetic MFMAs (dnag_gemm16.hip.h): the B registers hold frag16_pack fragments (fp16 hi/lo of 256 W),
-// every A value is scaled by 16 and split after the LayerNorm, three v_mfma_f32_32x32x16_f16 per 8 k values replace
-// eight v_mfma_f32_32x32x2_f32, and the accumulator is scaled back by 2^-12 before the epilogue.
+// F16: split-arithmetic MFMAs (dnag_gemm16.hip.h): the B registers hold frag16_pack fragments (fp16 hi/lo of sw W),
+// every A value is scaled by `sa` and split after the LayerNorm, three v_mfma_f32_32x32x16_f16 per 8 k values replace
+// eight v_mfma_f32_32x32x2_f32, and the accumulator is scaled back by inv = 1 / (sa sw) before the epilogue (the
+// packer's scale table of the layer, dnag_common.h ENC_SC_*).
 template <int K, int NTILES, int MT, int NW, bool LN, bool F16 = false, typename BLoad, typename Epi>
-__device__ __forceinline__ void run_jobs2(const float *A, int as, float (&b0)[K / 2], float (&b1)[K / 2], BLoad bload, Epi epi) {
+__device__ __forceinline__ void run_jobs2(const float *A, int as, float (&b0)[K / 2], float (&b1)[K / 2], BLoad bload, Epi epi,
+                                          float sa = 16.0f, float inv = 1.0f / 4096.0f) {
     typedef JobSplit<NTILES, MT, NW> JS;
     static_assert(JS::max_tiles() <= 2, "a wave's job chunk may span at most two column tiles");
     static_assert(!LN || K == DNAG_D, "fused LayerNorm needs the whole row in one K pass");
@@ -196,7 +203,7 @@ __device__ __forceinline__ void run_jobs2(const float *A, int as, float (&b0)[K 
                     h8 ahi, alo;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float v = a[8 * s + j] * 16.0f;
+                        const float v = a[8 * s + j] * sa;
                         const _Float16 hi = (_Float16)v;
                         ahi[j] = hi;
                         alo[j] = (_Float16)(v - (float)hi);
@@ -220,7 +227,7 @@ __device__ __forceinline__ void run_jobs2(const float *A, int as, float (&b0)[K 
         }
         if constexpr (F16) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] *= (1.0f / 4096.0f);
+            for (int i = 0; i < 16; ++i) acc[i] *= inv;
         }
         epi(mt, nt, r, h, acc);
     }
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                                                          const float *__restrict__ x, const float *__restrict__ temb,
                                                          int tstride, const float *__restrict__ mask, int mstride,
                                                          float *__restrict__ concat, float *__restrict__ attn0, int batch,
-                                                         int dbg_skip, const EncSave sv, const DropMasks dm) {
+                                                         const EncSave sv, const DropMasks dm) {
     typedef EncGeom<N, G, DFF> Ge;
     constexpr int R = Ge::R, MT = Ge::MT, RP = Ge::RP, HS = Ge::HS, QS = Ge::QS;
     constexpr int D = DNAG_D, DK = D / H;
@@ -285,6 +292,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
+    const float sa_concat = SPLIT ? P[lay.hsc + HEAD_SC_SA_CONCAT] : 0.f;
 #ifdef DNAG_ENC_STAMPS
     long long ts_[96];
     int nts_ = 0;
@@ -309,11 +317,6 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     const size_t wofs = F16 ? lay.delta16 : 0;     // weight matrices come from the fp16 fragment copy
     if (ft_qkv >= 0) load_w64(P + lay.layer0 + wofs + lay.l_wqkv, ft_qkv, bP);
 
-    {   // debug stagger experiment: bits 8-9 select which blocks sleep, bits 10-17 how long (x 8K cycles / 16)
-        const int mode = (dbg_skip >> 8) & 3, amt = (dbg_skip >> 10) & 255;
-        const int sel = mode == 1 ? (blockIdx.x >> 8) & 1 : mode == 2 ? (blockIdx.x >> 3) & 1 : mode == 3 ? (blockIdx.x >> 4) & 1 : 0;
-        if (sel) for (int i = 0; i < amt; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     // ---- stage inputs -------------------------------------------------------------------------
     float *xin = qkv;                   // [R][V] alias
     for (int i = tid; i < R * V; i += 256) {
@@ -351,17 +354,18 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     }
     __syncthreads();
     ENC_STAMP();
-    if (dbg_skip & 128) return;
+    if (DNAG_ENC_SKIP & 128) return;
     // row `lr` of this workgroup is a real graph row (SAVE stores skip the padding)
     auto live = [&](int lr) { return lr < R && g0 + lr / N < batch; };
 
     for (int l = 0; l < L; ++l) {
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
+        const float *SC = LP + lay.l_sc;          // power-of-two operand scales of this layer (dnag_common.h ENC_SC_*)
         // keep masks of this layer's sites for local row lr (DROP only; dead rows never read them)
         const uint8_t *KL = nullptr;
         if constexpr (DROP) KL = dm.keep + dm.rows * D + ((size_t)l * dm.rows + (size_t)g0 * N) * dm.per_layer;
         // ---- QKV = LN1(h) Wqkv'^T + bqkv' --------------------------------------------------------
-        if (!(dbg_skip & 1)) {
+        if (!(DNAG_ENC_SKIP & 1)) {
             const float *W = LP + wofs + lay.l_wqkv, *bias = LP + lay.l_bqkv;
             run_jobs2<D, NT_QKV, MT, 4, true, F16>(
                 hbuf, HS, bP, bQ, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
@@ -374,14 +378,14 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         qkv[lr * QS + col] = acc[i] + bv;
                         if constexpr (SAVE) if (live(lr)) sv.qkv[((size_t)l * sv.rows + (size_t)g0 * N + lr) * (3 * D) + col] = acc[i] + bv;
                     }
-                });
+                }, 16.0f, SC[ENC_SC_INV_QKV]);
         }
         constexpr bool PF_ATT = N <= 8;   // larger graphs need the registers for the attention rows
         if (PF_ATT && ft_o >= 0) load_w64(LP + wofs + lay.l_wo, ft_o, bP);   // lands while attention runs
         __syncthreads();
         ENC_STAMP();
         // ---- attention per (graph, head, query) ---------------------------------------------------
-        if (!(dbg_skip & 2))
+        if (!(DNAG_ENC_SKIP & 2))
         for (int it = tid; it < G * H * N; it += 256) {
             const int i = it % N, hd = (it / N) % H, g = it / (N * H);
             const int row = g * N + i;
@@ -477,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         __syncthreads();
         ENC_STAMP();
         // ---- h += attn Wo^T + bo ------------------------------------------------------------------
-        if (!(dbg_skip & 4)) {
+        if (!(DNAG_ENC_SKIP & 4)) {
             const float *W = LP + wofs + lay.l_wo, *bias = LP + lay.l_bo;
             run_jobs2<D, NT_O, MT, 4, false, F16>(
                 qkv, QS, bP, bP, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         *hp = hv;
                         if constexpr (SAVE) if (live(lr)) sv.h1[((size_t)l * sv.rows + (size_t)g0 * N + lr) * D + col] = hv;
                     }
-                });
+                }, SC[ENC_SC_SA_O], SC[ENC_SC_INV_O]);
         }
         if (ft_f1 >= 0) load_w64(LP + wofs + lay.l_w1, ft_f1, bQ);
         if (ft_f2 >= 0) {
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         __syncthreads();
         ENC_STAMP();
         // ---- hidden = relu(LN2(h) W1'^T + b1') -----------------------------------------------------
-        if (!(dbg_skip & 8)) {
+        if (!(DNAG_ENC_SKIP & 8)) {
             const float *W = LP + wofs + lay.l_w1, *bias = LP + lay.l_b1;
             run_jobs2<D, NT_F1, MT, 4, true, F16>(
                 hbuf, HS, bQ, bP, [&](int nt, int, int, float (&b)[D / 2]) { load_w64(W, nt, b); },
@@ -520,13 +524,13 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         qkv[lr * QS + col] = fv;
                         if constexpr (SAVE) if (live(lr)) sv.f[((size_t)l * sv.rows + (size_t)g0 * N + lr) * DFF + col] = fv;
                     }
-                });
+                }, 16.0f, SC[ENC_SC_INV_F1]);
         }
         if (l + 1 < L && ft_qkv >= 0) load_w64(LP + wofs + lay.layer_stride + lay.l_wqkv, ft_qkv, bP);   // next layer's first tile
         __syncthreads();
         ENC_STAMP();
         // ---- h += hidden W2^T + b2 ----------------------------------------------------------------
-        if (!(dbg_skip & 16)) {
+        if (!(DNAG_ENC_SKIP & 16)) {
             const float *W = LP + wofs + lay.l_w2, *bias = LP + lay.l_b2;
             run_jobs2<DFF, NT_F2, MT, 4, false, F16>(
                 qkv, QS, bR, bR,
@@ -544,12 +548,12 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         *hp = hv;
                         if constexpr (SAVE) if (live(lr)) sv.h[((size_t)(l + 1) * sv.rows + (size_t)g0 * N + lr) * D + col] = hv;
                     }
-                });
+                }, SC[ENC_SC_SA_F2], SC[ENC_SC_INV_F2]);
         }
         __syncthreads();
         ENC_STAMP();
         // ---- layer output norm (transformer.py:177) -> concat slice: 16 lanes per row, DPP statistics ----
-        if (!(dbg_skip & 64)) {
+        if (!(DNAG_ENC_SKIP & 64)) {
             const float *og = LP + lay.l_ong, *ob = LP + lay.l_onb;
             const int sub = tid & 15, slot = tid >> 4;
             const v4f g4 = *reinterpret_cast<const v4f *>(og + 4 * sub);
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         h4_t hi4, lo4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float sv16 = o4[e] * 16.0f;           // SPLIT_SA (dnag_gemm16.hip.h)
+                            const float sv16 = o4[e] * sa_concat;
                             const _Float16 hi = (_Float16)sv16;
                             hi4[e] = hi;
                             lo4[e] = (_Float16)(sv16 - (float)hi);

@@ -2,13 +2,15 @@
 // Included by dnag_lib.hip.
 //
 // An fp32 value a is carried as two fp16 numbers, s a = hi + lo with hi = fp16(s a) and lo = fp16(s a - hi):
-// 22 significant bits.  The power-of-two scale s (16 for activations, 256 for weights) lifts lo out of the fp16
+// 22 significant bits.  The power-of-two scale s (16 for activations, 256 for weights, smaller when the packer's
+// worst-case bound of the operand asks for it: dnag_common.h "Operand scales") lifts lo out of the fp16
 // subnormals for the magnitudes that matter (below |a| = 2^-6 resp. 2^-10 the absolute error is 2^-29 resp. 2^-33:
 // nothing against the O(1) terms of the same dot product) and is divided out, exactly, in the epilogue.
 // A product of two such values is  hi hi' + hi lo' + lo hi'  (+ lo lo', dropped: 2^-22 relative, below fp32
 // rounding), i.e. THREE v_mfma_f32_32x32x16_f16 instead of one chain of v_mfma_f32_32x32x2_f32 -- 16 x the rate
 // per instruction, so 5.3 x the fp32 MFMA peak.  Every fp16 product is exact in the fp32 accumulator.
-// Range: |a| < 4094 for activations (LayerNorm outputs and ELU activations here), |w| < 255 for weights.
+// Range: none to respect.  The scales of the sampling path come from the packed blob (CateLayout::hsc, l_sc), where
+// the host packer derived them from the weights so that s |a| < 60000 for every reachable activation and weight.
 //
 // Operand storage ("split-pair" rows): a row of K values takes 4K bytes like fp32; every group of 8 values is
 // 16 bytes of hi followed by 16 bytes of lo, which is exactly one MFMA A/B fragment each (lane (r, h) of a
@@ -20,9 +22,8 @@
 #include "dnag_common.h"
 #include "dnag_head.hip.h"
 
-#define SPLIT_SA 16.0f        // activation scale
-#define SPLIT_SW 256.0f       // weight scale
-#define SPLIT_OUT_INV (1.0f / (SPLIT_SA * SPLIT_SW))
+#define SPLIT_SA 16.0f        // default activation scale (IN_F32 GEMMs without a device-side maximum)
+#define SPLIT_SW 256.0f       // default weight scale
 
 static inline __host__ __device__ void split16(float a, float scale, _Float16 &hi, _Float16 &lo) {
     const float v = a * scale;
@@ -32,13 +33,13 @@ static inline __host__ __device__ void split16(float a, float scale, _Float16 &h
 // index of value k of a split-pair row, in units of _Float16: hi at split_at(k), lo at split_at(k) + 8
 static inline __host__ __device__ size_t split_at(size_t k) { return (k >> 3) * 16 + (k & 7); }
 
-// host: W [rows][K] fp32 -> split-pair rows scaled by SPLIT_SW (K % 8 == 0), same byte size
-static inline void split_pack(const float *W, size_t rows, size_t K, float *out) {
+// host: W [rows][K] fp32 -> split-pair rows scaled by sw (K % 8 == 0), same byte size
+static inline void split_pack(const float *W, size_t rows, size_t K, float *out, float sw) {
     _Float16 *o = reinterpret_cast<_Float16 *>(out);
     for (size_t r = 0; r < rows; ++r)
         for (size_t k = 0; k < K; ++k) {
             _Float16 hi, lo;
-            split16(W[r * K + k], SPLIT_SW, hi, lo);
+            split16(W[r * K + k], sw, hi, lo);
             o[r * 2 * K + split_at(k)] = hi;
             o[r * 2 * K + split_at(k) + 8] = lo;
         }
@@ -46,13 +47,13 @@ static inline void split_pack(const float *W, size_t rows, size_t K, float *out)
 
 #ifdef __HIPCC__
 // split-pair activation rows -> fp32 (tests and the concat_out of dnag_cate_forward)
-__global__ void unsplit_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows, int K) {
+__global__ void unsplit_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows, int K, const float *__restrict__ sa) {
     const _Float16 *p = reinterpret_cast<const _Float16 *>(in);
     const size_t n = rows * (size_t)K;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / K, k = e - r * K;
         const size_t at = r * 2 * (size_t)K + split_at(k);
-        out[e] = ((float)p[at] + (float)p[at + 8]) * (1.0f / SPLIT_SA);
+        out[e] = ((float)p[at] + (float)p[at + 8]) / *sa;
     }
 }
 
@@ -88,6 +89,8 @@ struct SplitF32Args {
     const float *amax_a, *amax_w;     // device, or null: SPLIT_SA / SPLIT_SW
     const float *aux;                 // ACT_MUL_ELUGRAD: aux = elu(z), multiply by elu'(z)
     float *amax_out;                  // optional: max |C| (float bits, atomicMax) for a later GEMM's operand scale
+    const float *sc;                  // !IN_F32: device table of this GEMM's scales (dnag_common.h HEAD_SC_F0 / _F1):
+                                      // [0] 1 / (sa_in sw), [1] sa of the output it writes, [2] sw of W3, [3] 1 / ([1] [2])
 };
 
 // *out = max(*out, max |x[i]|) as float bits (non-negative floats order like unsigned integers); *out starts at 0
@@ -137,9 +140,12 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
     const float *Ag = A + (size_t)(tm * BM + lrow) * lda + lk + kbase;
     const float *Wg = W + (size_t)(tn * BN + lrow) * ldw + lk + kbase;
     float sa = SPLIT_SA, sw = SPLIT_SW;
+    float out_inv = 0.f, sa_out = 0.f, sw3 = 0.f, out_inv3 = 0.f;
     if constexpr (IN_F32) {
         if (fa.amax_a) sa = pow2_scale(*fa.amax_a);
         if (fa.amax_w) sw = pow2_scale(*fa.amax_w);
+    } else {
+        out_inv = fa.sc[0]; sa_out = fa.sc[1]; sw3 = fa.sc[2]; out_inv3 = fa.sc[3];
     }
 
     f32x16 acc[4][2];
@@ -268,7 +274,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
         for (int i = tid; i < BN; i += 512) b1s[i] = bias ? bias[tn * BN + i] : 0.f;
         __syncthreads();
         // final.linears.2 on the matrix cores too: P[v][row] = sum_col W3[v][col] x[col][row] as 32x32x16 fp16 MFMAs in
-        // the same split arithmetic (W3 scaled by SPLIT_SW, x by SPLIT_SA).  A lane's 16 accumulator registers of one
+        // the same split arithmetic (W3 scaled by sc[2], x by sc[1]).  A lane's 16 accumulator registers of one
         // tile all belong to its batch row, so registers 8s .. 8s+7 ARE its B fragment of step s; the A fragment holds
         // W3 at the columns those registers stand for (rows >= V of the 32-row operand are zero).
         h8 w3h[2][2], w3l[2][2];
@@ -285,9 +291,9 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     _Float16 hi, lo;
-                    split16(wa[u], SPLIT_SW, hi, lo);
+                    split16(wa[u], sw3, hi, lo);
                     w3h[t][s2][u] = hi; w3l[t][s2][u] = lo;
-                    split16(wb[u], SPLIT_SW, hi, lo);
+                    split16(wb[u], sw3, hi, lo);
                     w3h[t][s2][4 + u] = hi; w3l[t][s2][4 + u] = lo;
                 }
             }
@@ -307,10 +313,10 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
                         const v4f b4 = *reinterpret_cast<const v4f *>(b1s + c0);
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            float x = fmaf(acc[i][t][8 * s2 + 4 * q + u], SPLIT_OUT_INV, b4[u]);
+                            float x = fmaf(acc[i][t][8 * s2 + 4 * q + u], out_inv, b4[u]);
                             if (ACT == ACT_ELU) x = x > 0.f ? x : __expf(x) - 1.0f;
                             _Float16 hi, lo;
-                            split16(x, SPLIT_SA, hi, lo);
+                            split16(x, sa_out, hi, lo);
                             xh[4 * q + u] = hi; xl[4 * q + u] = lo;
                         }
                     }
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if ((e & 3) + 8 * (e >> 2) < V && acc_row(e, h) < V)
-                    red[(wn * BM + wm * 128 + i * 32 + r) * V + acc_row(e, h)] = pa[e] * SPLIT_OUT_INV;
+                    red[(wn * BM + wm * 128 + i * 32 + r) * V + acc_row(e, h)] = pa[e] * out_inv3;
         }
         __syncthreads();
         float *dst = parts + ((size_t)tn * M + (size_t)tm * BM) * V;
@@ -372,14 +378,14 @@ __global__ __launch_bounds__(512, 1) void gemm_split_kernel(const float *__restr
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const size_t row = (size_t)(row0 + acc_row(e, h));
-                float v = fmaf(acc[i][j][e], SPLIT_OUT_INV, bv);
+                float v = fmaf(acc[i][j][e], out_inv, bv);
                 if (ACT == ACT_ELU) v = v > 0.f ? v : __expf(v) - 1.0f;
                 if constexpr (!OUT_SPLIT) {
                     C[row * Nout + col] = v;
                 } else {
                     // lanes 2q, 2q+1 hold adjacent columns: the even lane stores both hi halves, the odd lane both lo
                     _Float16 hi, lo;
-                    split16(v, SPLIT_SA, hi, lo);
+                    split16(v, sa_out, hi, lo);
                     const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, hi), lb = (uint32_t)__builtin_bit_cast(uint16_t, lo);
                     const uint32_t send = (r & 1) ? hb : lb;
                     const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]

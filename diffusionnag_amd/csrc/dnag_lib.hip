@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -116,10 +117,38 @@ static void fold_ln(const float *W, const float *b, const float *gam, const floa
     }
 }
 
+static float amax_of(const float *w, size_t n) {
+    float m = 0.f;
+    for (size_t i = 0; i < n; ++i) m = fmaxf(m, fabsf(w[i]));
+    return m;
+}
+// worst-case |y_c| of y = W u + b over LayerNorm outputs u (no affine: ||u||_2 <= sqrt(d), dnag_common.h)
+static float bound_ln_linear(const float *W, const float *b, size_t rows, size_t d) {
+    double m = 0.0;
+    for (size_t r = 0; r < rows; ++r) {
+        double q = 0.0;
+        for (size_t k = 0; k < d; ++k) q += (double)W[r * d + k] * (double)W[r * d + k];
+        m = fmax(m, sqrt((double)d) * sqrt(q) + fabs((double)b[r]));
+    }
+    return (float)(m * 1.0001);
+}
+// worst-case |y_c| of y = W a + b over inputs with |a_k| <= amax
+static float bound_l1_linear(const float *W, const float *b, size_t rows, size_t K, float amax) {
+    double m = 0.0;
+    for (size_t r = 0; r < rows; ++r) {
+        double q = 0.0;
+        for (size_t k = 0; k < K; ++k) q += fabs((double)W[r * K + k]);
+        m = fmax(m, q * (double)amax + fabs((double)b[r]));
+    }
+    return (float)(m * 1.0001);
+}
+
 // state_dict order -> CateLayout; `pe` may be NULL (no positional table: zeros)
 static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *pe, const float *freq, float *out) {
     const CateLayout y = cate_layout(c);
     const size_t d = y.d, V = y.V, dff = y.dff, L = y.L, F = y.F, Hd = y.Hd;
+    for (size_t i = 0, n = dnag_cate_state_floats(&c); i < n; ++i)
+        if (!std::isfinite(s[i])) return fail(DNAG_E_ARG, "state_flat[%zu] = %g is not finite", i, (double)s[i]);
     memset(out, 0, y.total * sizeof(float));
     size_t o = 0;
     auto take = [&](size_t dst, size_t n) { memcpy(out + dst, s + o, n * sizeof(float)); o += n; };
@@ -127,36 +156,65 @@ static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *
     take(y.t1_w, 4 * d * d); take(y.t1_b, 4 * d);
     take(y.t2_w, 4 * d * d); take(y.t2_b, d);
     std::vector<float> tmp((3 * d > dff ? 3 * d : dff) * d);
+    // Power-of-two operand scales of the split arithmetic, from the weights alone (dnag_common.h, "Operand scales")
     for (size_t l = 0; l < L; ++l) {
         float *LP = out + y.layer0 + l * y.layer_stride;
+        float *SC = LP + y.l_sc;
         const float *ln1g = s + o, *ln1b = s + o + d; o += 2 * d;
         for (int j = 0; j < 3; ++j) {   // Q, K, V
             fold_ln(s + o, s + o + d * d, ln1g, ln1b, d, d, tmp.data() + j * d * d, LP + y.l_bqkv + j * d);
             o += d * d + d;
         }
+        const float sw_qkv = weight_scale(amax_of(tmp.data(), 3 * d * d));
+        const float sa_o = act_scale(bound_ln_linear(tmp.data() + 2 * d * d, LP + y.l_bqkv + 2 * d, d, d));   // attention output: convex combinations of V rows
         frag_pack(tmp.data(), 3 * d, d, d, LP + y.l_wqkv);
-        frag16_pack(tmp.data(), 3 * d, d, d, LP + y.delta16 + y.l_wqkv);
+        frag16_pack(tmp.data(), 3 * d, d, d, LP + y.delta16 + y.l_wqkv, sw_qkv);
+        const float sw_o = weight_scale(amax_of(s + o, d * d));
         frag_pack(s + o, d, d, d, LP + y.l_wo);
-        frag16_pack(s + o, d, d, d, LP + y.delta16 + y.l_wo); o += d * d;
+        frag16_pack(s + o, d, d, d, LP + y.delta16 + y.l_wo, sw_o); o += d * d;
         memcpy(LP + y.l_bo, s + o, d * sizeof(float)); o += d;
         const float *ln2g = s + o, *ln2b = s + o + d; o += 2 * d;
         fold_ln(s + o, s + o + dff * d, ln2g, ln2b, dff, d, tmp.data(), LP + y.l_b1); o += dff * d + dff;
+        const float sw_1 = weight_scale(amax_of(tmp.data(), dff * d));
+        const float sa_f2 = act_scale(bound_ln_linear(tmp.data(), LP + y.l_b1, dff, d));   // relu does not raise the bound
         frag_pack(tmp.data(), dff, d, d, LP + y.l_w1);
-        frag16_pack(tmp.data(), dff, d, d, LP + y.delta16 + y.l_w1);
+        frag16_pack(tmp.data(), dff, d, d, LP + y.delta16 + y.l_w1, sw_1);
+        const float sw_2 = weight_scale(amax_of(s + o, d * dff));
         frag_pack(s + o, d, dff, dff, LP + y.l_w2);
-        frag16_pack(s + o, d, dff, dff, LP + y.delta16 + y.l_w2); o += d * dff;
+        frag16_pack(s + o, d, dff, dff, LP + y.delta16 + y.l_w2, sw_2); o += d * dff;
         memcpy(LP + y.l_b2, s + o, d * sizeof(float)); o += d;
+        SC[ENC_SC_INV_QKV] = 1.0f / (16.0f * sw_qkv);
+        SC[ENC_SC_SA_O] = sa_o;
+        SC[ENC_SC_INV_O] = 1.0f / (sa_o * sw_o);
+        SC[ENC_SC_INV_F1] = 1.0f / (16.0f * sw_1);
+        SC[ENC_SC_SA_F2] = sa_f2;
+        SC[ENC_SC_INV_F2] = 1.0f / (sa_f2 * sw_2);
     }
+    float cbound = 0.f;               // |concat| <= 8 max|gamma| + max|beta| over the output norms
     for (size_t l = 0; l < L; ++l) {   // encoder_f.norms.l
         float *LP = out + y.layer0 + l * y.layer_stride;
+        cbound = fmaxf(cbound, sqrtf((float)d) * amax_of(s + o, d) + amax_of(s + o + d, d));
         memcpy(LP + y.l_ong, s + o, d * sizeof(float)); o += d;
         memcpy(LP + y.l_onb, s + o, d * sizeof(float)); o += d;
     }
     take(y.f0_w, Hd * F); take(y.f0_b, Hd);
     take(y.f1_w, Hd * Hd); take(y.f1_b, Hd);
     take(y.f2_w, V * Hd); take(y.f2_b, V);
-    split_pack(out + y.f0_w, Hd, F, out + y.f0_s);
-    split_pack(out + y.f1_w, Hd, Hd, out + y.f1_s);
+    {
+        float *H = out + y.hsc;
+        const float sa_c = act_scale(cbound);
+        const float sw0 = weight_scale(amax_of(out + y.f0_w, Hd * F)), sw1 = weight_scale(amax_of(out + y.f1_w, Hd * Hd));
+        const float sw3 = weight_scale(amax_of(out + y.f2_w, V * Hd));
+        // |elu(z)| <= max(|z|, 1)
+        const float h1b = fmaxf(1.0f, bound_l1_linear(out + y.f0_w, out + y.f0_b, Hd, F, cbound));
+        const float h2b = fmaxf(1.0f, bound_l1_linear(out + y.f1_w, out + y.f1_b, Hd, Hd, h1b));
+        const float sa1 = act_scale(h1b), sa2 = act_scale(h2b);
+        H[HEAD_SC_SA_CONCAT] = sa_c;
+        H[HEAD_SC_F0 + 0] = 1.0f / (sa_c * sw0); H[HEAD_SC_F0 + 1] = sa1;
+        H[HEAD_SC_F1 + 0] = 1.0f / (sa1 * sw1); H[HEAD_SC_F1 + 1] = sa2; H[HEAD_SC_F1 + 2] = sw3; H[HEAD_SC_F1 + 3] = 1.0f / (sa2 * sw3);
+        split_pack(out + y.f0_w, Hd, F, out + y.f0_s, sw0);
+        split_pack(out + y.f1_w, Hd, Hd, out + y.f1_s, sw1);
+    }
     if (o != dnag_cate_state_floats(&c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_cate_state_floats(&c));
     if (pe) memcpy(out + y.pe, pe, (size_t)y.N * d * sizeof(float));
     memcpy(out + y.freq, freq, (d / 2) * sizeof(float));
@@ -184,30 +242,38 @@ extern "C" int dnag_pred_pack(const dnag_pred_dims *c, const float *s, const flo
     const size_t g = y.g, lh = y.lh, hs = y.hs, nz = y.nz;
     memset(out, 0, y.total * sizeof(float));
     size_t o = 0;
+    for (size_t i = 0, n = dnag_pred_state_floats(c); i < n; ++i)
+        if (!std::isfinite(s[i])) return fail(DNAG_E_ARG, "state_flat[%zu] = %g is not finite", i, (double)s[i]);
     std::vector<float> tr(g * (g > lh ? g : lh));
+    // every split-arithmetic matrix gets its own power-of-two scale (dnag_common.h "Operand scales"); the kernel divides
+    // it out through the table at y.wsc.  The activations' scales are derived at run time (predictor_kernel, phase_scale).
     for (int l = 0; l < y.L; ++l) {
         const size_t in = l == 0 ? (size_t)y.V : g;
         for (int w = 0; w < 2; ++w) {
             const float *W = s + o; o += in * g;   // [in][g]
+            const float sw = weight_scale(amax_of(W, in * g));
+            out[y.wsc + 2 * l + w] = 1.0f / sw;
             if (l == 0) memcpy(out + (w ? y.w2_0 : y.w1_0), W, in * g * sizeof(float));
             frag_pack(W, in, g, g, out + (w ? y.w2b[l] : y.w1b[l]));
-            frag16_pack(W, in, g, g, out + y.delta16 + (w ? y.w2b[l] : y.w1b[l]));
+            frag16_pack(W, in, g, g, out + y.delta16 + (w ? y.w2b[l] : y.w1b[l]), sw);
             if (l > 0) {
                 for (size_t i = 0; i < in; ++i)
                     for (size_t k = 0; k < g; ++k) tr[k * in + i] = W[i * g + k];
                 frag_pack(tr.data(), g, in, in, out + (w ? y.w2f[l] : y.w1f[l]));
-                frag16_pack(tr.data(), g, in, in, out + y.delta16 + (w ? y.w2f[l] : y.w1f[l]));
+                frag16_pack(tr.data(), g, in, in, out + y.delta16 + (w ? y.w2f[l] : y.w1f[l]), sw);
             }
         }
     }
     {
         const float *W = s + o; o += lh * g;   // fc1 [lh][g]
+        const float sw = weight_scale(amax_of(W, lh * g));
+        out[y.wsc + 2 * y.L] = 1.0f / sw;
         frag_pack(W, lh, g, g, out + y.fc1f);
-        frag16_pack(W, lh, g, g, out + y.delta16 + y.fc1f);
+        frag16_pack(W, lh, g, g, out + y.delta16 + y.fc1f, sw);
         for (size_t i = 0; i < lh; ++i)
             for (size_t k = 0; k < g; ++k) tr[k * lh + i] = W[i * g + k];
         frag_pack(tr.data(), g, lh, lh, out + y.fc1b);
-        frag16_pack(tr.data(), g, lh, lh, out + y.delta16 + y.fc1b);
+        frag16_pack(tr.data(), g, lh, lh, out + y.delta16 + y.fc1b, sw);
     }
     memcpy(out + y.t1_w, s + o, 4 * g * g * sizeof(float)); o += 4 * g * g;
     memcpy(out + y.t1_b, s + o, 4 * g * sizeof(float)); o += 4 * g;
@@ -439,8 +505,21 @@ extern "C" int dnag_timing_end(void) {
     return 0;
 }
 
-// debug only: DNAG_ENC_SKIP / DNAG_PRED_SKIP are phase bit masks for timing ablations (outputs become wrong)
-static int env_int(const char *name) { const char *v = getenv(name); return v ? atoi(v) : 0; }
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device setting: set it once per (kernel, device), from whichever
+// thread launches first there (two threads racing set the same value twice)
+struct LdsAttr {
+    std::atomic<size_t> bytes[64];
+    LdsAttr() { for (auto &b : bytes) b.store(0); }
+};
+static int ensure_lds(LdsAttr &a, const void *kern, size_t bytes) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::atomic<size_t> &have = a.bytes[dev & 63];
+    if (have.load(std::memory_order_acquire) >= bytes) return 0;
+    HIP_TRY(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have.store(bytes, std::memory_order_release);
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------------------
 // launches
@@ -461,7 +540,7 @@ static int launch_gemm_t(const float *A, const float *W, const float *bias, floa
 }
 
 static int launch_gemm(const float *A, const float *W, const float *bias, float *C, size_t M, int Nout, int K, bool timed,
-                       size_t real_rows, hipStream_t st, const float *W3 = nullptr, int V = 0) {
+                       size_t real_rows, hipStream_t st, const float *sc, const float *W3 = nullptr, int V = 0) {
     int slot = -1;
     if (timed) {
         std::lock_guard<std::mutex> lk(g_tm_mu);
@@ -480,15 +559,13 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
     auto k7 = gemm_split_kernel<ACT_ELU, false, 1, 7>;      // final.linears.1 + final.linears.2 fused, NAS-Bench-201
     auto k9 = gemm_split_kernel<ACT_ELU, false, 1, 9>;      // same, OFA
     auto k0 = gemm_split_kernel<ACT_ELU, true, 0>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k7), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k9), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
-        attr_set = true;
-    }
+    static LdsAttr a7, a9, a0;
+    if (int rc = ensure_lds(a7, reinterpret_cast<const void *>(k7), Ge::lds_bytes)) return rc;
+    if (int rc = ensure_lds(a9, reinterpret_cast<const void *>(k9), Ge::lds_bytes)) return rc;
+    if (int rc = ensure_lds(a0, reinterpret_cast<const void *>(k0), Ge::lds_bytes)) return rc;
     SplitF32Args nofa;
     memset(&nofa, 0, sizeof(nofa));
+    nofa.sc = sc;
     if (timed) {
         if (V != 7 && V != 9) return fail(DNAG_E_ARG, "fused head GEMM is built for 7 or 9 output columns, got %d", V);
         // C receives the partial sums [Nout / 256][M][V] of final.linears.2
@@ -511,12 +588,10 @@ static int launch_gemm32(const float *A, int lda, const float *amax_a, const flo
         return fail(DNAG_E_ARG, "split gemm shape %zu x %d x %d (lda %d ldw %d split %d) not tile aligned", M, Nout, K, lda, ldw, splitk);
     if (splitk > 1 && (ACT != ACT_NONE || bias)) return fail(DNAG_E_ARG, "split-K gemm takes no bias / activation");
     auto kern = gemm_split_kernel<ACT, false, TAG, 0, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)Ge::lds_bytes));
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), Ge::lds_bytes)) return rc;
     SplitF32Args fa;
+    fa.sc = nullptr;
     fa.lda = lda; fa.ldw = ldw; fa.ldc = ldc; fa.amax_a = amax_a; fa.amax_w = amax_w; fa.aux = aux; fa.amax_out = amax_out;
     const int grid = (int)(M / Ge::BM) * (Nout / Ge::BN);
     hipLaunchKernelGGL(kern, dim3(grid, splitk), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr,
@@ -539,17 +614,14 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
     typedef EncGeom<N, G, 128> Ge;
     const size_t lds = Ge::lds_floats * sizeof(float);
     auto kern = encoder_kernel<N, V, G, 8, 128, true, false, false, true, true>;   // split-arithmetic linears, concat in split-pair rows
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
     const int grid = (batch + G - 1) / G;
     EncSave none;
     memset(&none, 0, sizeof(none));
     DropMasks nodrop;
     memset(&nodrop, 0, sizeof(nodrop));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch, env_int("DNAG_ENC_SKIP"), none, nodrop);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, attn0, batch, none, nodrop);
     LAUNCH_CHECK();
     return 0;
 }
@@ -577,13 +649,10 @@ static int launch_predictor(const PredLayout &lay, const float *P, const float *
     typedef PredGeom<8, 7> Ge;
     const size_t lds = Ge::lds_bytes(lay.hs, lay.L);
     auto kern = predictor_kernel<8, 7>;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
     const int grid = (batch + Ge::G - 1) / Ge::G;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, d_mu, y, grad, batch, env_int("DNAG_PRED_SKIP"));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, d_mu, y, grad, batch);
     LAUNCH_CHECK();
     return 0;
 }
@@ -593,9 +662,9 @@ static int run_score_body(const dnag_cate_dims &c, const CateLayout &lay, const 
                           int tstride, const float *mask, int mstride, float *ws, const WsLayout &w, float *attn0, int batch,
                           hipStream_t st) {
     if (int rc = launch_encoder(c, lay, P, x, temb, tstride, mask, mstride, ws + w.concat, attn0, batch, st)) return rc;
-    if (int rc = launch_gemm(ws + w.concat, P + lay.f0_s, P + lay.f0_b, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st)) return rc;
+    if (int rc = launch_gemm(ws + w.concat, P + lay.f0_s, P + lay.f0_b, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st, P + lay.hsc + HEAD_SC_F0)) return rc;
     // final.linears.1 with final.linears.2 fused into its epilogue: ws.h2 receives [Hd / 256][rows_pad][V] partial sums
-    if (int rc = launch_gemm(ws + w.h1, P + lay.f1_s, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st, P + lay.f2_w, lay.V)) return rc;
+    if (int rc = launch_gemm(ws + w.h1, P + lay.f1_s, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st, P + lay.hsc + HEAD_SC_F1, P + lay.f2_w, lay.V)) return rc;
     return 0;
 }
 
@@ -620,7 +689,7 @@ extern "C" int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, c
     a.parts = ws + w.h2; a.nparts = lay.Hd / SplitGeom::BN; a.part_stride = w.rows_pad * (size_t)lay.V;
     if (int rc = launch_exit(*d, lay, packed, ws + w.h2, a, st)) return rc;
     if (concat_out) {   // the workspace holds split-pair rows; hand back plain fp32
-        hipLaunchKernelGGL(unsplit_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, lay.F);
+        hipLaunchKernelGGL(unsplit_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, lay.F, packed + lay.hsc + HEAD_SC_SA_CONCAT);
         LAUNCH_CHECK();
     }
     return 0;
@@ -638,6 +707,51 @@ extern "C" int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *pack
         return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, nt * lay.g * sizeof(float));
     hipStream_t st = (hipStream_t)stream;
     float *temb = (float *)workspace;
+    if (int rc = launch_time_embed(time_cond, (int)nt, lay.g, packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, temb, st)) return rc;
+    return launch_predictor(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, d_mu, y, grad, batch, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dnag_pred_forward_grad without a workspace argument and without any allocation (include/dnag.h): the time-embedding
+// staging that dnag_pred_forward_grad keeps in the caller's workspace lives in a file-scope device array instead.
+// `scratch` is a host-side stand-in for the symbol: the device address of each GPU's copy comes from
+// hipGetSymbolAddress, once per device, and only that pointer is ever handed to a kernel.
+// ---------------------------------------------------------------------------------------------
+#define NOALLOC_MAX_BATCH DNAG_NOALLOC_MAX_BATCH
+static __device__ __align__(256) float scratch[(size_t)NOALLOC_MAX_BATCH * PRED_GH];   // temb [batch][144]: 2.25 MiB per GPU
+static float *g_scratch_ptr[64];
+static std::mutex g_scratch_mu;
+
+static int scratch_for_current_device(float **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(DNAG_E_ARG, "device ordinal %d is beyond the 64 this library keeps scratch pointers for", dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        float *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(DNAG_E_HIP, "hipGetSymbolAddress(scratch) returned a null address on device %d", dev);
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int dnag_pred_forward_grad_noalloc(const dnag_pred_dims *d, const float *packed, const float *x, const float *time_cond,
+                                              int time_stride, const float *mask, int mask_stride, const float *d_mu, float *y,
+                                              float *grad, int batch, void *stream) {
+    if (int rc = check_pred(d)) return rc;
+    if (!packed || !x || !time_cond || !mask || !d_mu) return fail(DNAG_E_ARG, "NULL pointer");
+    if (batch < 1) return fail(DNAG_E_ARG, "batch=%d", batch);
+    if (batch > NOALLOC_MAX_BATCH)
+        return fail(DNAG_E_ARG, "batch=%d exceeds DNAG_NOALLOC_MAX_BATCH=%d of the allocation-free entry point; use dnag_pred_forward_grad with a workspace",
+                    batch, NOALLOC_MAX_BATCH);
+    float *temb = nullptr;
+    if (int rc = scratch_for_current_device(&temb)) return rc;
+    const PredLayout lay = pred_layout(*d);
+    const size_t nt = time_stride ? batch : 1;
+    hipStream_t st = (hipStream_t)stream;
+    // every temb row the predictor kernel reads (nt rows) is rewritten by this launch: nothing of an earlier call survives
     if (int rc = launch_time_embed(time_cond, (int)nt, lay.g, packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, temb, st)) return rc;
     return launch_predictor(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, d_mu, y, grad, batch, st);
 }
@@ -669,15 +783,12 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
         typedef EncGeom<PC_N, PC_G, 32> Ge;
         const size_t lds = Ge::lds_floats * sizeof(float);
         auto kern = encoder_kernel<PC_N, PC_V, PC_G, 2, 32, false, true, false, false, true>;   // saved activations, split-arithmetic linears
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        static LdsAttr attr;
+        if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
         DropMasks nodrop;
         memset(&nodrop, 0, sizeof(nodrop));
         hipLaunchKernelGGL(kern, dim3((batch + PC_G - 1) / PC_G), dim3(256), lds, st, P, e, x, temb, tstride, mask, mstride,
-                           ws + w.concat, (float *)nullptr, batch, 0, sv, nodrop);
+                           ws + w.concat, (float *)nullptr, batch, sv, nodrop);
         LAUNCH_CHECK();
     }
     // final MLP (cate.py:323), flatten, regeress MLP (:325-326), pred_fc (:348)
@@ -713,11 +824,8 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
         typedef PcbGeom<PC_N, PC_G, 2, 32> Ge;
         const size_t lds = Ge::lds_floats * sizeof(float);
         auto kern = predcate_enc_bwd_kernel<PC_N, PC_V, PC_G, 2, 32>;
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        static LdsAttr attr;
+        if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
         hipLaunchKernelGGL(kern, dim3((batch + PC_G - 1) / PC_G), dim3(256), lds, st, P, y, sv, ws + w.dconcat, mask, mstride, grad, batch);
         LAUNCH_CHECK();
     }
@@ -747,6 +855,12 @@ extern "C" int dnag_predcate_forward_grad(const dnag_predcate_dims *d, const flo
 // ---------------------------------------------------------------------------------------------
 // predictor-corrector loop
 // ---------------------------------------------------------------------------------------------
+#define LABEL_CHUNK 256
+struct LabelChunk { float v[LABEL_CHUNK]; };
+__global__ void put_labels_kernel(float *__restrict__ dst, const LabelChunk c, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+
 extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     if (!p) return fail(DNAG_E_ARG, "args is NULL");
     if (int rc = check_cate(p->cate_dims)) return rc;
@@ -803,8 +917,14 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             return fail(DNAG_E_ARG, "sched[%d].std = %g is not positive", i, row[DNAG_SCHED_STD]);
         labels[i] = row[DNAG_SCHED_LABEL];
     }
-    HIP_TRY(hipMemcpyAsync(ws + w.labels, labels.data(), S * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));   // `labels` is pageable host memory that dies with this call
+    // the labels travel as kernel arguments (copied at launch): no host buffer has to outlive this call, nothing waits
+    for (int i = 0; i < S; i += LABEL_CHUNK) {
+        LabelChunk ch;
+        const int n = S - i < LABEL_CHUNK ? S - i : LABEL_CHUNK;
+        memcpy(ch.v, labels.data() + i, n * sizeof(float));
+        hipLaunchKernelGGL(put_labels_kernel, dim3(1), dim3(LABEL_CHUNK), 0, st, ws + w.labels + i, ch, n);
+        LAUNCH_CHECK();
+    }
     if (int rc = launch_time_embed(ws + w.labels, S, lay.d, p->cate_packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, ws + w.temb_s, st)) return rc;
     if (guided_pc) {
         const CateLayout &e = pclay.enc;
@@ -944,7 +1064,7 @@ static TrainWs train_ws(const dnag_cate_dims &c, int batch) {
     w.scratch = take(64 * big);
     w.splitk = take(8 * Hd * Hd);
     w.lossp = take(TRAIN_LOSS_BLOCKS);
-    w.amax = take(4);            // max |dH2|, max |dH1| (float bits), for the dynamic operand scales of the split GEMM
+    w.amax = take(8);            // max |dH2|, |dH1|, |W0|, |W1|, |concat|, |H1| (float bits): dynamic operand scales of the split GEMMs
     w.total = o;
     return w;
 }
@@ -1007,13 +1127,10 @@ static int launch_train_encoder(bool drop, int nblk, const float *P, const CateL
     const size_t lds = Ge::lds_floats * sizeof(float);
     auto k_drop = encoder_kernel<8, 7, G, 8, 128, true, true, true, false, true>;      // split-arithmetic linears
     auto k_nodrop = encoder_kernel<8, 7, G, 8, 128, true, true, false, false, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_drop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nodrop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(drop ? k_drop : k_nodrop, dim3(nblk), dim3(256), lds, st, P, e, xt, temb, 1, mask, mstride, concat, (float *)nullptr, B, 0, sv, dm);
+    static LdsAttr a_drop, a_nodrop;
+    if (int rc = ensure_lds(a_drop, reinterpret_cast<const void *>(k_drop), lds)) return rc;
+    if (int rc = ensure_lds(a_nodrop, reinterpret_cast<const void *>(k_nodrop), lds)) return rc;
+    hipLaunchKernelGGL(drop ? k_drop : k_nodrop, dim3(nblk), dim3(256), lds, st, P, e, xt, temb, 1, mask, mstride, concat, (float *)nullptr, B, sv, dm);
     LAUNCH_CHECK();
     return 0;
 }
@@ -1025,11 +1142,8 @@ static int launch_train_enc_bwd(int nblk, const float *P, const TrainLayout &tl,
     typedef TrbGeom<8, G, 8, 128> Ge;
     const size_t lds = Ge::lds_floats * sizeof(float);
     auto kern = cate_enc_bwd_kernel<8, 7, G, 8, 128>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static LdsAttr attr;
+    if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, P, tl, sv, xt, dconcat, mask, mstride, dm, part, gl, dtau, B);
     LAUNCH_CHECK();
     return 0;
@@ -1068,6 +1182,8 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     HIP_TRY(cpy(e.f2_b, S + sl.f2_b, (size_t)V));
     HIP_TRY(cpy(e.pe, p->tables, (size_t)N * d));
     HIP_TRY(cpy(e.freq, p->tables + (size_t)N * d, (size_t)d / 2));
+    hipLaunchKernelGGL(train_scales_kernel, dim3(L), dim3(256), 0, st, S, sl, P, tl);
+    LAUNCH_CHECK();
     hipLaunchKernelGGL(train_pack_layers_kernel, dim3(32, L), dim3(256), 0, st, S, sl, P, tl);
     LAUNCH_CHECK();
     if (p->grads) {
@@ -1092,10 +1208,18 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
         return rc;
     // ---- 3. head MLP and loss ------------------------------------------------------------------------------------
     // all six big GEMMs of the step run on the split-arithmetic fp16 MFMA kernel with fp32 operands split on the fly
-    HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 4 * sizeof(float), st));
-    float *amax_dh2 = ws + w.amax, *amax_dh1 = ws + w.amax + 1;
-    if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.concat, F, nullptr, P + e.f0_w, F, nullptr, P + e.f0_b, ws + w.h1, Hd, nullptr, rows_pad, Hd, F, 1, st)) return rc;
-    if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.h1, Hd, nullptr, P + e.f1_w, Hd, nullptr, P + e.f1_b, ws + w.h2, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
+    // every operand's power-of-two scale comes from its largest magnitude, measured on the device (no range to respect)
+    HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 8 * sizeof(float), st));
+    float *amax_dh2 = ws + w.amax, *amax_dh1 = ws + w.amax + 1, *amax_w0 = ws + w.amax + 2, *amax_w1 = ws + w.amax + 3;
+    float *amax_cc = ws + w.amax + 4, *amax_h1 = ws + w.amax + 5;
+    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, st, P + e.f0_w, (size_t)Hd * F, amax_w0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, st, P + e.f1_w, (size_t)Hd * Hd, amax_w1);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(amax_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, rows * (size_t)F, amax_cc);
+    LAUNCH_CHECK();
+    if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.concat, F, amax_cc, P + e.f0_w, F, amax_w0, P + e.f0_b, ws + w.h1, Hd, nullptr, rows_pad, Hd, F, 1, st, amax_h1)) return rc;
+    if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.h1, Hd, amax_h1, P + e.f1_w, Hd, amax_w1, P + e.f1_b, ws + w.h2, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
     {
         ExitArgs a;
         memset(&a, 0, sizeof(a));
@@ -1123,24 +1247,24 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = launch_transpose(ws + w.dh2, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
     if (int rc = launch_transpose(ws + w.h1, rows_pad, Hd, Hd, ws + w.T2, rows_pad, rows_pad, st)) return rc;
     // weight gradients reduce over the rows: few output tiles, long K -> split K so that the grid fills the chip
-    auto wgrad_gemm = [&](const float *At, const float *amax_at, const float *Bt, int Mo, int No, float *dst) -> int {
+    auto wgrad_gemm = [&](const float *At, const float *amax_at, const float *Bt, const float *amax_bt, int Mo, int No, float *dst) -> int {
         const int tiles = (Mo / SplitGeom::BM) * (No / SplitGeom::BN);
         int split = 1;
         while (split < 16 && tiles * split < 256 && (rows_pad / GEMM_BK) % (2 * split) == 0) split *= 2;
-        if (int rc = launch_gemm32<ACT_NONE, 4>(At, (int)rows_pad, amax_at, Bt, (int)rows_pad, nullptr, nullptr, ws + w.splitk, No, nullptr, Mo, No,
+        if (int rc = launch_gemm32<ACT_NONE, 4>(At, (int)rows_pad, amax_at, Bt, (int)rows_pad, amax_bt, nullptr, ws + w.splitk, No, nullptr, Mo, No,
                                                 (int)rows_pad, split, st))
             return rc;
         const size_t n = (size_t)Mo * No;
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, ws + w.splitk, split, n, n, dst, 1.0f);
         return hipGetLastError() == hipSuccess ? 0 : fail(DNAG_E_HIP, "reduce_parts_kernel launch failed");
     };
-    if (int rc = wgrad_gemm(ws + w.T1, amax_dh2, ws + w.T2, Hd, Hd, G + sl.f1_w)) return rc;   // dW2 = dH2^T H1
-    if (int rc = launch_gemm32<ACT_MUL_ELUGRAD, 3>(ws + w.dh2, Hd, amax_dh2, P + tl.f1T, Hd, nullptr, nullptr, ws + w.dh1, Hd, ws + w.h1, rows_pad, Hd, Hd, 1, st, amax_dh1)) return rc;
+    if (int rc = wgrad_gemm(ws + w.T1, amax_dh2, ws + w.T2, amax_h1, Hd, Hd, G + sl.f1_w)) return rc;   // dW2 = dH2^T H1
+    if (int rc = launch_gemm32<ACT_MUL_ELUGRAD, 3>(ws + w.dh2, Hd, amax_dh2, P + tl.f1T, Hd, amax_w1, nullptr, ws + w.dh1, Hd, ws + w.h1, rows_pad, Hd, Hd, 1, st, amax_dh1)) return rc;
     if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, st)) return rc;
     if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
     if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, st)) return rc;
-    if (int rc = wgrad_gemm(ws + w.T1, amax_dh1, ws + w.T2, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
-    if (int rc = launch_gemm32<ACT_NONE, 3>(ws + w.dh1, Hd, amax_dh1, P + tl.f0T, Hd, nullptr, nullptr, ws + w.dconcat, F, nullptr, rows_pad, F, Hd, 1, st)) return rc;
+    if (int rc = wgrad_gemm(ws + w.T1, amax_dh1, ws + w.T2, amax_cc, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
+    if (int rc = launch_gemm32<ACT_NONE, 3>(ws + w.dh1, Hd, amax_dh1, P + tl.f0T, Hd, amax_w0, nullptr, ws + w.dconcat, F, nullptr, rows_pad, F, Hd, 1, st)) return rc;
     // ---- 5. encoder backward -----------------------------------------------------------------------------------------
     if (int rc = train_g(B) == 8 ? launch_train_enc_bwd<8>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st)
                                  : launch_train_enc_bwd<4>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st))

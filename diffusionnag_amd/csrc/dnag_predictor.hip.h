@@ -18,6 +18,10 @@
 #include "dnag_common.h"
 #include "dnag_encoder.hip.h"
 
+#ifndef DNAG_PRED_SKIP
+#define DNAG_PRED_SKIP 0    // debug builds only (-DDNAG_PRED_SKIP=<mask>): phases switched off for timing ablations (wrong results)
+#endif
+
 #define PRED_GH 144        // gcn_hidden (configs/tr_meta_surrogate.py:97)
 #define PRED_HS 148        // LDS row stride of [R][144] buffers (148 % 64 == 20: conflict-free b128 reads)
 #define PRED_NT 5          // ceil(144 / 32) column tiles
@@ -50,10 +54,10 @@ struct PredGeom {
 // B2's fragments fetched chunk by chunk while the first tile's MFMAs run (into the registers B1's chunks leave).  The A rows sit in LDS as split-pair rows (dnag_gemm16.hip.h: per 8 values 16 B of fp16 hi, 16 B of lo),
 // written once by the mixing phase with the phase's power-of-two scale `sa`, so a step is two ds_read_b128 and three
 // MFMAs, no conversion work; a1p / a2p point at the lane's row and K/2 half.  F2 is a frag16_pack matrix
-// (dnag_common.h), nt its column tile.
+// (dnag_common.h), nt its column tile; inv1 / inv2 = 1 / (sa sw) of the two products (sw: PredLayout::wsc).
 template <int K>
 __device__ __forceinline__ void two_tiles16(const float *a1p, const float *a2p, const float (&b1)[K / 2], const float *F2,
-                                            int nt, float sa, f32x16 &acc1, f32x16 &acc2) {
+                                            int nt, float inv1, float inv2, f32x16 &acc1, f32x16 &acc2) {
     typedef const __attribute__((address_space(1))) v4f *gv4p;
     static_assert(K % 16 == 0, "8 k values per lane half and step");
     const float *p2 = F2 + ((size_t)nt * (K / 8) * 64 + (threadIdx.x & 63)) * 4;
@@ -79,9 +83,8 @@ __device__ __forceinline__ void two_tiles16(const float *a1p, const float *a2p, 
     }
 #pragma unroll
     for (int s = 0; s < K / 16; ++s) step(a2p, b2, s, acc2);
-    const float inv = 1.0f / (sa * 256.0f);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc1[i] *= inv; acc2[i] *= inv; }
+    for (int i = 0; i < 16; ++i) { acc1[i] *= inv1; acc2[i] *= inv2; }
 }
 
 template <int N, int V>
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                                                                  const float *__restrict__ x, const float *__restrict__ temb,
                                                                  int tstride, const float *__restrict__ mask, int mstride,
                                                                  const float *__restrict__ d_mu, float *__restrict__ y,
-                                                                 float *__restrict__ grad, int batch, int dbg_skip) {
+                                                                 float *__restrict__ grad, int batch) {
     typedef PredGeom<N, V> Ge;
     static_assert(N == 8, "adjacency mixing is written for 8-node graphs");
     constexpr int G = Ge::G, R = Ge::R, MT = Ge::MT, HS = PRED_HS, GH = PRED_GH, NT = PRED_NW * 64, LH = 128, XS = Ge::XS;
@@ -140,6 +143,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     };
     auto phase_scale = [&](int ph) { return pow2_scale(__uint_as_float(amaxv[ph])); };
     const float *P16 = P + lay.delta16;
+    const float *WSC = P + lay.wsc;           // 1 / sw of every split-arithmetic matrix (dnag_pred_pack)
 
     // ---- inputs ---------------------------------------------------------------------------------
     for (int i = tid; i < R * XS; i += NT) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
         if (tid == 0) colsum_max = __float_as_uint(m);
     }
-    if (!(dbg_skip & 1)) {
+    if (!(DNAG_PRED_SKIP & 1)) {
         for (int i = tid; i < R * XS; i += NT) {
             const int r = i / XS, v = i - r * XS;
             const int g = r / N, n = r - g * N;
@@ -339,10 +343,10 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         __syncthreads();
         PRED_STAMP(6);
         uint32_t *bl = bits + (size_t)l * BL;
-        if (!(dbg_skip & 4)) {
+        if (!(DNAG_PRED_SKIP & 4)) {
             // each wave owns one (column tile, row tile); Z1 and Z2 back to back
             f32x16 acc1, acc2;
-            two_tiles16<GH>(u1p, u2p, bw1, W2t, my_nt, sa, acc1, acc2);
+            two_tiles16<GH>(u1p, u2p, bw1, W2t, my_nt, WSC[2 * l] / sa, WSC[2 * l + 1] / sa, acc1, acc2);
             const int col = my_nt * 32 + lr;
             float hmax = 0.f;
             uint32_t w = 0u;
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     }
 
     // ---- head forward: graphs become the rows 0..G-1 of a 32-row MFMA tile ---------------------------
-    if (!(dbg_skip & 8)) {
+    if (!(DNAG_PRED_SKIP & 8)) {
         const int ph = phase++;
         float vmax = 0.f;
         for (int i = tid; i < G * GH; i += NT) {
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                     const int row = acc_row(i, h);
                     if (row < G) U2[row * HS + nt * 32 + r] = acc[i];
                 }
-            }, sa);
+            }, sa, WSC[2 * L]);
         __syncthreads();
         PRED_STAMP(9);
         for (int i = tid; i < G * hs; i += NT) {   // tanh(W0a a + c0)  (p0_at [LH][hs])
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     PRED_STAMP(11);
 
     // ---- head backward ----------------------------------------------------------------------------
-    if (!(dbg_skip & 16)) {
+    if (!(DNAG_PRED_SKIP & 16)) {
         for (int i = tid; i < G * hs; i += NT) {   // dpre = w2 (1 - tanh^2)
             const int g = i / hs, j = i - g * hs;
             const float t = tv[g * TS + j];
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                     }
                 }
                 note_max(dmax, ph + 1);    // max |dH_L|: scale bound of the first backward mixing
-            }, sa);
+            }, sa, WSC[2 * L]);
     }
     __syncthreads();
     PRED_STAMP(14);
@@ -471,9 +475,9 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         prefetch_b(W1, bw1);
         __syncthreads();
         PRED_STAMP(16);
-        if (!(dbg_skip & 64)) {
+        if (!(DNAG_PRED_SKIP & 64)) {
             f32x16 acc1, acc2;
-            two_tiles16<GH>(u1p, u2p, bw1, W2, my_nt, sa, acc1, acc2);
+            two_tiles16<GH>(u1p, u2p, bw1, W2, my_nt, WSC[2 * l] / sa, WSC[2 * l + 1] / sa, acc1, acc2);
             const int col = my_nt * 32 + lr;
             float dmax = 0.f;
             if (col < GH) {
@@ -494,12 +498,12 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     const float sa0 = mix_bwd(0, ph0);
     __syncthreads();
     PRED_STAMP(18);
-    if (!(dbg_skip & 128) && wv < MT) {   // one row tile per wave
+    if (!(DNAG_PRED_SKIP & 128) && wv < MT) {   // one row tile per wave
         const float *W1 = P16 + lay.w1b[0], *W2 = P16 + lay.w2b[0];   // fp16 fragments [V -> 32][GH], one tile
         float b1[GH / 2];
         load_frag<GH>(W1, 0, b1);
         f32x16 acc1, acc2;
-        two_tiles16<GH>(U1 + (wv * 32 + lr) * HS + lh * (GH / 2), U2 + (wv * 32 + lr) * HS + lh * (GH / 2), b1, W2, 0, sa0, acc1, acc2);
+        two_tiles16<GH>(U1 + (wv * 32 + lr) * HS + lh * (GH / 2), U2 + (wv * 32 + lr) * HS + lh * (GH / 2), b1, W2, 0, WSC[0] / sa0, WSC[1] / sa0, acc1, acc2);
         if (lr < V) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {

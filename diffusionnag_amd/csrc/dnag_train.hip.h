@@ -142,13 +142,73 @@ __device__ __forceinline__ size_t frag16_at(size_t K, size_t row, size_t k) {
     const size_t KH = K / 2, h = k / KH, kk = k - h * KH;
     return (((row >> 5) * (K / 8) + 2 * (kk >> 3)) * 64 + 32 * h + (row & 31)) * 8 + (kk & 7);
 }
-__device__ __forceinline__ void frag16_put(float *base, size_t K, size_t row, size_t k, float w) {
+__device__ __forceinline__ void frag16_put(float *base, size_t K, size_t row, size_t k, float w, float sw) {
     _Float16 *o = reinterpret_cast<_Float16 *>(base);
-    const float v = w * 256.0f;
+    const float v = w * sw;
     const _Float16 hi = (_Float16)v;
     const size_t at = frag16_at(K, row, k);
     o[at] = hi;
     o[at + 64 * 8] = (_Float16)(v - (float)hi);
+}
+
+// Power-of-two operand scales of one encoder layer (dnag_common.h "Operand scales", what cate_pack_impl derives on the
+// host), from the current parameters: grid (L), 256 threads; runs before train_pack_layers_kernel, which reads them.
+__global__ __launch_bounds__(256) void train_scales_kernel(const float *__restrict__ S, const CateStateLayout sl,
+                                                           float *__restrict__ P, const TrainLayout tl) {
+    const int l = blockIdx.x, t = threadIdx.x;
+    const int d = tl.enc.d, dff = tl.enc.dff;
+    const float *SL = S + sl.layer0 + (size_t)l * sl.layer_stride;
+    float *SC = P + tl.enc.layer0 + (size_t)l * tl.enc.layer_stride + tl.enc.l_sc;
+    __shared__ unsigned int m[6];     // amax qkv', o, w1', w2; bound of V rows, bound of the FFN hidden (float bits)
+    if (t < 6) m[t] = 0u;
+    __syncthreads();
+    auto note = [&](int i, float v) { atomicMax(&m[i], __float_as_uint(v)); };
+    // folded row r of W (W diag(gamma)): largest magnitude, and the worst case of |W' u + b'| over LayerNorm outputs u
+    auto row_stats = [&](const float *W, const float *b, const float *gam, const float *bet, float &amax, float &bound) {
+        float a = 0.f, q = 0.f, bb = *b;
+        for (int k = 0; k < d; ++k) {
+            const float w = W[k] * gam[k];
+            a = fmaxf(a, fabsf(w));
+            q = fmaf(w, w, q);
+            bb = fmaf(W[k], bet[k], bb);
+        }
+        amax = a;
+        bound = (sqrtf((float)d) * sqrtf(q) + fabsf(bb)) * 1.0001f;
+    };
+    if (t < 3 * d) {
+        const int which = t / d, r = t - which * d;
+        const size_t srcw = which == 0 ? sl.s_wq : which == 1 ? sl.s_wk : sl.s_wv;
+        const size_t srcb = which == 0 ? sl.s_bq : which == 1 ? sl.s_bk : sl.s_bv;
+        float a, bd;
+        row_stats(SL + srcw + (size_t)r * d, SL + srcb + r, SL + sl.s_ln1g, SL + sl.s_ln1b, a, bd);
+        note(0, a);
+        if (which == 2) note(4, bd);
+    }
+    if (t < dff) {
+        float a, bd;
+        row_stats(SL + sl.s_w1 + (size_t)t * d, SL + sl.s_b1 + t, SL + sl.s_ln2g, SL + sl.s_ln2b, a, bd);
+        note(2, a);
+        note(5, bd);
+    }
+    if (t < d) {
+        float a = 0.f, a2 = 0.f;
+        for (int k = 0; k < d; ++k) a = fmaxf(a, fabsf(SL[sl.s_wo + (size_t)t * d + k]));
+        for (int k = 0; k < dff; ++k) a2 = fmaxf(a2, fabsf(SL[sl.s_w2 + (size_t)t * dff + k]));
+        note(1, a);
+        note(3, a2);
+    }
+    __syncthreads();
+    if (t == 0) {
+        const float sw_qkv = weight_scale(__uint_as_float(m[0])), sw_o = weight_scale(__uint_as_float(m[1]));
+        const float sw_1 = weight_scale(__uint_as_float(m[2])), sw_2 = weight_scale(__uint_as_float(m[3]));
+        const float sa_o = act_scale(__uint_as_float(m[4])), sa_f2 = act_scale(__uint_as_float(m[5]));
+        SC[ENC_SC_INV_QKV] = 1.0f / (16.0f * sw_qkv);
+        SC[ENC_SC_SA_O] = sa_o;
+        SC[ENC_SC_INV_O] = 1.0f / (sa_o * sw_o);
+        SC[ENC_SC_INV_F1] = 1.0f / (16.0f * sw_1);
+        SC[ENC_SC_SA_F2] = sa_f2;
+        SC[ENC_SC_INV_F2] = 1.0f / (sa_f2 * sw_2);
+    }
 }
 
 __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__restrict__ S, const CateStateLayout sl,
@@ -157,6 +217,10 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
     const size_t d = tl.enc.d, dff = tl.enc.dff;
     const float *SL = S + sl.layer0 + (size_t)l * sl.layer_stride;
     float *LF = P + tl.enc.layer0 + (size_t)l * tl.enc.layer_stride;
+    // weight scales of this layer, back from train_scales_kernel's table (all exact powers of two)
+    const float *SC = LF + tl.enc.l_sc;
+    const float sw_qkv = 1.0f / (16.0f * SC[ENC_SC_INV_QKV]), sw_o = 1.0f / (SC[ENC_SC_SA_O] * SC[ENC_SC_INV_O]);
+    const float sw_1 = 1.0f / (16.0f * SC[ENC_SC_INV_F1]), sw_2 = 1.0f / (SC[ENC_SC_SA_F2] * SC[ENC_SC_INV_F2]);
     float *LB = P + tl.bl0 + (size_t)l * tl.bl_stride;
     float *L16 = LF + tl.enc.delta16;      // fp16 fragment copy of the forward matrices (split-arithmetic forward)
     const size_t n_qkv = 3 * d * d, n_o = d * d, n_1 = dff * d, n_2 = d * dff;
@@ -169,7 +233,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t srcw = which == 0 ? sl.s_wq : which == 1 ? sl.s_wk : sl.s_wv;
             const float v = SL[srcw + rk] * SL[sl.s_ln1g + k];
             LF[tl.enc.l_wqkv + frag_at(d, which * d + r, k)] = v;
-            frag16_put(L16 + tl.enc.l_wqkv, d, which * d + r, k, v);
+            frag16_put(L16 + tl.enc.l_wqkv, d, which * d + r, k, v, sw_qkv);
             LB[tl.b_wqkvT + frag_at(3 * d, k, which * d + r)] = v;
             continue;
         }
@@ -178,7 +242,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t r = j / d, k = j - r * d;
             const float v = SL[sl.s_wo + j];
             LF[tl.enc.l_wo + frag_at(d, r, k)] = v;
-            frag16_put(L16 + tl.enc.l_wo, d, r, k, v);
+            frag16_put(L16 + tl.enc.l_wo, d, r, k, v, sw_o);
             LB[tl.b_woT + frag_at(d, k, r)] = v;
             continue;
         }
@@ -187,7 +251,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t r = j / d, k = j - r * d;
             const float v = SL[sl.s_w1 + j] * SL[sl.s_ln2g + k];
             LF[tl.enc.l_w1 + frag_at(d, r, k)] = v;
-            frag16_put(L16 + tl.enc.l_w1, d, r, k, v);
+            frag16_put(L16 + tl.enc.l_w1, d, r, k, v, sw_1);
             LB[tl.b_w1T + frag_at(dff, k, r)] = v;
             continue;
         }
@@ -196,7 +260,7 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             const size_t r = j / dff, k = j - r * dff;
             const float v = SL[sl.s_w2 + j];
             LF[tl.enc.l_w2 + frag_at(dff, r, k)] = v;
-            frag16_put(L16 + tl.enc.l_w2, dff, r, k, v);
+            frag16_put(L16 + tl.enc.l_w2, dff, r, k, v, sw_2);
             LB[tl.b_w2T + frag_at(d, k, r)] = v;
             continue;
         }

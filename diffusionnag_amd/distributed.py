@@ -60,11 +60,11 @@ def configure_sampler_shard(sampler, start: int, n_node: int, n_vocab: int, seed
 def gather_samples(x_local: torch.Tensor, total: int) -> torch.Tensor:
     """All-gather the per-rank samples ``[count_r, N, V]`` into ``[total, N, V]`` in rank order.
     Ragged shards are padded to the largest shard for the collective and trimmed afterwards."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         if x_local.shape[0] != total:
             raise ValueError("single process: local shard must be the whole batch")
         return x_local
-    world = dist.get_world_size()
+    world = dist.get_world_size()   # a one-rank group still runs the collective (RCCL on a GPU tensor)
     counts: List[int] = [shard_batch(total, r, world)[1] for r in range(world)]
     if x_local.shape[0] != counts[dist.get_rank()]:
         raise ValueError(f"rank {dist.get_rank()} holds {x_local.shape[0]} graphs, expected {counts[dist.get_rank()]}")

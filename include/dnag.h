@@ -120,6 +120,17 @@ int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *packed, const f
                            const float *d_mu, float *y, float *grad, int batch,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* dnag_pred_forward_grad for callers that cannot allocate or bring a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and results as
+ * dnag_pred_forward_grad minus the workspace: the time-embedding staging ([batch][144] floats) lives in a device
+ * array inside the library (2.25 MiB per GPU, held until the process ends).  batch > DNAG_NOALLOC_MAX_BATCH is
+ * rejected with DNAG_E_ARG.  The call allocates nothing (no hipMalloc / hipFree, no torch).  Every call on one GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on one stream do not. */
+#define DNAG_NOALLOC_MAX_BATCH 4096
+int dnag_pred_forward_grad_noalloc(const dnag_pred_dims *d, const float *packed, const float *x,
+                                   const float *time_cond, int time_stride, const float *mask, int mask_stride,
+                                   const float *d_mu, float *y, float *grad, int batch, void *stream);
+
 /* Same for the OFA surrogate: replaces MetaPredictorCATE.forward with cached D_mu
  * (models/cate.py:311-360) and get_classifier_grad_fn (models/utils.py:126-147). */
 int dnag_predcate_forward_grad(const dnag_predcate_dims *d, const float *packed, const float *x,

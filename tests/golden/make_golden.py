@@ -1,6 +1,7 @@
 """Capture golden vectors from the REFERENCE implementation (run in the build container only).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            # every fixture
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py margin     # only the fixtures whose name contains "margin"
 
 Imports ``/root/reference/NAS-Bench-201`` (read-only, unmodified), loads the seeded
 synthetic weights of ``diffusionnag_amd.synthetic`` into the reference's own modules
@@ -78,7 +79,11 @@ def main():
 
     out = {}
 
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+
     def save(name, **arrs):
+        if only is not None and only not in name:
+            return
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
                                      for k, v in arrs.items()})
@@ -259,6 +264,12 @@ def main():
                 preset="contractive", tape_seed=14, classifier_scale=100.0)
     run_sampler("pc_guided_nb201_contractive_n1000", sde_N=1000, n_run=1000, B=4, guided=True, mask=closure,
                 preset="contractive", tape_seed=15, classifier_scale=100.0, full_record=False, beta_max=5.0)
+
+    # decision margins: B=64 complete guided trajectories on three tapes; the test compares the discretised
+    # architectures bit for bit and reports how far the final states sit from the 0.5 threshold
+    for k, tape_seed in enumerate((31, 32, 33)):
+        run_sampler(f"pc_guided_nb201_contractive_margin{k}", sde_N=100, n_run=100, B=64, guided=True, mask=closure,
+                    preset="contractive", tape_seed=tape_seed, classifier_scale=100.0, full_record=False)
 
     for k, v in out.items():
         print(f"{k}.npz  {v/1024:.1f} KiB")

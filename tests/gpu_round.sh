@@ -12,8 +12,8 @@ run() {   # run <seconds> <log> <cmd...>
 }
 for step in "$@"; do
 case $step in
-  new)    run 300 new_tests.log python -u -m pytest tests/test_gpu_train.py tests/test_gpu_validity.py -q -s --timeout 120 --timeout-method thread; tail -25 gpurun_out/new_tests.log ;;
-  suite)  run 600 gpu_tests.log python -u -m pytest tests -m gpu -q --timeout 120 --timeout-method thread; tail -5 gpurun_out/gpu_tests.log ;;
+  new)    run 400 new_tests.log python -u -m pytest tests/test_gpu_range.py tests/test_gpu_shard.py tests/wip_no_alloc.py -v -s -m gpu --timeout 120 --timeout-method thread; tail -40 gpurun_out/new_tests.log ;;
+  suite)  run 900 gpu_tests.log python -u -m pytest tests -m gpu -x -v --timeout 120 --timeout-method thread; tail -15 gpurun_out/gpu_tests.log ;;
   bench)  run 300 bench_default.log python bench.py; tail -1 gpurun_out/bench_default.log ;;
   train)  run 200 bench_train.log python bench.py --workload train; tail -1 gpurun_out/bench_train.log ;;
   ofa)    run 300 bench_ofa.log python bench.py --workload ofa --no-cpu-baseline; tail -1 gpurun_out/bench_ofa.log ;;

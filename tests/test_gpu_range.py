@@ -1,0 +1,108 @@
+"""Operand range of the split arithmetic (fp32 products on fp16 hi/lo pairs, dnag_gemm16.hip.h): the packer derives
+every power-of-two scale from the weights (dnag_common.h "Operand scales"), so no weight or activation magnitude can
+overflow fp16.  Checkpoints with weights and activations far beyond what 256 |w| < 65504 and 16 |a| < 65504 allow must
+match the oracle to the same 5e-6 of the tensor's max as ordinary ones (reference models/cate.py:55-73, :145-164)."""
+
+import numpy as np
+import pytest
+import torch
+
+from diffusionnag_amd import cate as _cate, digcn_meta as _dm  # noqa: F401
+from diffusionnag_amd import mutils, synthetic
+from diffusionnag_amd.specs import CateDims, PredictorDims
+from tests.helpers import predictor_config, score_config
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def close(a, b, rel, what):
+    a = np.asarray(a.detach().cpu(), np.float64)
+    b = np.asarray(b.detach().cpu(), np.float64)
+    assert np.isfinite(a).all(), f"{what}: non-finite values"
+    e, scale = np.abs(a - b).max(), np.abs(b).max()
+    assert e <= rel * scale, f"{what}: max|err| {e:.3e} > {rel:.1e} * {scale:.3e}"
+
+
+def _inputs(B, seed):
+    rs = np.random.RandomState(seed)
+    X = torch.from_numpy(rs.standard_normal((B, 8, 7)).astype(np.float32))
+    t = torch.from_numpy((rs.uniform(1e-3, 1, B) * 999).astype(np.float32))
+    m = torch.from_numpy((rs.uniform(0, 1, (B, 8, 8)) < 0.4).astype(np.float32))
+    return X, t, m
+
+
+def _run(sd, X, t, m):
+    from oracle import dnag_oracle as O
+    model = mutils.create_model(score_config(CateDims(), DEV))
+    model.load_state_dict(sd)
+    model.eval()
+    out, concat, _ = model(X.to(DEV), t.to(DEV), m.to(DEV), return_concat=True)
+    rec = {}
+    ref = O.cate_forward(sd, X, t, m, record=rec)
+    return out, concat, (ref, rec["concat"])
+
+
+def test_head_weights_and_activations_beyond_the_fixed_scales():
+    """One final.linears.1 weight of 300 (256 * 300 overflows fp16) and a final.linears.0 unit whose pre-activation
+    exceeds 5000 (16 * 5000 overflows fp16): VERDICT r01 item 1."""
+    from oracle import dnag_oracle as O
+    sd = synthetic.cate_state_dict(CateDims(), seed=4, perturb_norms=True)
+    sd["final.linears.1.weight"][5, 7] = 300.0
+    sd["final.linears.0.weight"][3] *= 4.0e4          # row 3: weights up to ~1400, pre-activations of several thousand
+    X, t, m = _inputs(24, 21)
+    out, concat, (ref, ref_concat) = _run(sd, X, t, m)
+    h1 = torch.nn.functional.linear(ref_concat, sd["final.linears.0.weight"], sd["final.linears.0.bias"])
+    assert float(h1[..., 3].abs().max()) > 5000.0       # the case really is out of the old range
+    close(concat, ref_concat, 5e-6, "concat")
+    close(out, ref, 5e-6, "out")
+
+
+def test_encoder_weights_and_norm_affine_beyond_the_fixed_scales():
+    sd = synthetic.cate_state_dict(CateDims(), seed=5, perturb_norms=True)
+    p = "graph_encoder.encoder_f.layers."
+    sd[p + "0.self_attn.attn.linears.2.weight"] *= 3000.0          # V projection: attention outputs in the thousands
+    sd[p + "0.self_attn.attn.linears.3.weight"] *= 1.0e-3
+    sd[p + "1.feed_forward.feed_forward.w_1.weight"] *= 6000.0     # FFN hidden in the tens of thousands
+    sd[p + "1.feed_forward.feed_forward.w_2.weight"] *= 1.0e-4
+    sd[p + "2.self_attn.attn.linears.0.weight"][7, 9] = 500.0      # single large entries
+    sd[p + "3.feed_forward.feed_forward.w_2.weight"][1, 100] = -700.0
+    sd["graph_encoder.encoder_f.norms.4.weight"] *= 900.0          # |concat| up to ~7000 in slice 4
+    sd["final.linears.0.weight"][:, 4 * 64:5 * 64] *= 1.0e-3
+    sd["final.linears.2.weight"][2, 11] = 400.0
+    X, t, m = _inputs(24, 22)
+    out, concat, (ref, ref_concat) = _run(sd, X, t, m)
+    assert float(ref_concat.abs().max()) > 4094.0
+    close(concat, ref_concat, 5e-6, "concat")
+    close(out, ref, 5e-6, "out")
+
+
+def test_surrogate_weights_beyond_the_fixed_scale():
+    from oracle import dnag_oracle as O
+    d = PredictorDims()
+    sdp = synthetic.predictor_state_dict(d, seed=9)
+    sdp["gcn.1.weight1"][3, 5] = 400.0
+    sdp["gcn.2.weight2"] *= 2000.0
+    sdp["gcn.3.weight1"] *= 5.0e-4
+    sdp["gcn.3.weight2"] *= 5.0e-4
+    sdp["fc1.weight"][2, 2] = -300.0
+    clf = mutils.create_model(predictor_config(d, DEV))
+    clf.load_state_dict(sdp)
+    clf.eval()
+    task = synthetic.synthetic_task(10, 20, seed=3)
+    D_mu = O.set_encode(sdp, task)
+    X, t, m = _inputs(13, 23)
+    y = clf(X.to(DEV), t.to(DEV), m.to(DEV), task=task.to(DEV))
+    g = clf.input_grad(X.to(DEV), t.to(DEV), m.to(DEV), task=task.to(DEV))
+    close(y, O.predictor_forward(sdp, X, t, m, D_mu), 1e-5, "y")
+    close(g, O.classifier_grad(sdp, X, t / 999, m, D_mu), 1e-5, "grad")
+
+
+def test_non_finite_weights_are_refused_by_name():
+    sd = synthetic.cate_state_dict(CateDims(), seed=0)
+    sd["final.linears.1.weight"][0, 0] = float("inf")
+    model = mutils.create_model(score_config(CateDims(), DEV))
+    model.load_state_dict(sd)
+    X, t, m = _inputs(2, 1)
+    with pytest.raises(RuntimeError, match="not finite"):
+        model.eval()(X.to(DEV), t.to(DEV), m.to(DEV))

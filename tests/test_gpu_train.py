@@ -73,7 +73,8 @@ def test_dsm_step_against_reference_golden(name):
         if key.startswith("grad:"):
             k = key[5:]
             got = params[k[:-4]].grad[:8] if k.endswith("[:8]") else params[k].grad
-            e = rel_err(got.cpu().numpy(), g[key], floor)
+            # only the key bias is zero analytically (softmax is shift invariant): its gradient is rounding noise
+            e = rel_err(got.cpu().numpy(), g[key], floor if ".attn.linears.1.bias" in k else 0.0)
             assert e <= 5e-5, f"{key}: {e:.3e}"
 
 
@@ -104,7 +105,7 @@ def test_dsm_step_against_oracle_ragged_batch(sde_kind, B, reduce_mean):
     worst = ("", 0.0)
     floor = 2e-6 * max(float(v.abs().max()) for v in want.values())
     for k, prm in model.named_parameters():
-        e = rel_err(prm.grad.cpu().numpy(), want[k].numpy(), floor)
+        e = rel_err(prm.grad.cpu().numpy(), want[k].numpy(), floor if ".attn.linears.1.bias" in k else 0.0)
         if e > worst[1]:
             worst = (k, e)
         assert e <= 5e-5, f"{k}: {e:.3e}"

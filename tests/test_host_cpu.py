@@ -86,7 +86,7 @@ def test_cate_pack_folds_layernorm_into_linear():
     # layout constants restated from csrc/dnag_common.h
     d, V, dff = 64, 7, 128
     layer0 = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d
-    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d
+    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d + 8     # ... + the 8 operand scales
     rs = np.random.RandomState(0)
     h = rs.standard_normal((5, d))
     for l in (0, 7):
@@ -108,13 +108,21 @@ def test_cate_pack_folds_layernorm_into_linear():
     # derived tables = the oracle's restatement of the reference constructors
     n_split = 1536 * 768 + 1536 * 1536                 # split-pair copies of final.linears.{0,1} ...
     n_l16 = 12 * stride                                # ... and the fp16-fragment copy of the layer blocks close the blob
-    tail = packed[-(8 * 64 + 32) - n_split - n_l16: -n_split - n_l16]
+    n_hsc = 16                                         # head GEMM operand scales, between the two
+    tail = packed[-(8 * 64 + 32) - n_split - n_hsc - n_l16: -n_split - n_hsc - n_l16]
     assert np.allclose(tail[: 8 * 64], O.positional_table(8, 64, False).numpy().ravel(), atol=0)
     assert np.allclose(tail[8 * 64:], _cate.timestep_frequencies(64).numpy(), atol=0)
     # split-pair rows (csrc/dnag_gemm16.hip.h): groups of 8 values = 8 fp16 hi then 8 fp16 lo of 256 w; hi + lo
     # reproduces the fp32 weight to 22 significant bits
     raw_all = model._pack_host(model._state_flat().contiguous()).numpy()
-    raw = raw_all[-n_split - n_l16: -n_l16]
+    raw = raw_all[-n_split - n_hsc - n_l16: -n_hsc - n_l16]
+    # ordinary weights: every operand scale is the default (16 for activations, 256 for weights)
+    hsc = raw_all[-n_hsc - n_l16: -n_l16]
+    assert hsc[0] == 16.0 and hsc[4] == 1.0 / 4096 and hsc[5] == 16.0
+    assert list(hsc[8:12]) == [1.0 / 4096, 16.0, 256.0, 1.0 / 4096]
+    for l in range(12):
+        sc = raw_all[layer0 + l * stride + stride - 8: layer0 + (l + 1) * stride]
+        assert list(sc[:6]) == [1.0 / 4096, 16.0, 1.0 / 4096, 1.0 / 4096, 16.0, 1.0 / 4096], (l, sc)
     halves = raw[: 1536 * 768].view(np.float16).reshape(1536, 768 // 8, 2, 8).astype(np.float64)
     w0 = sd["final.linears.0.weight"].double().numpy()
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 768) / 256.0
@@ -133,6 +141,59 @@ def test_cate_pack_folds_layernorm_into_linear():
                 r_, h_ = lane & 31, lane >> 5
                 rec[nt * 32 + r_, h_ * 32 + 8 * (q >> 1): h_ * 32 + 8 * (q >> 1) + 8] += fr[nt, q, lane]
     assert np.abs(rec / 256.0 - Wo).max() <= 2.0 ** -21 * np.abs(Wo).max()
+
+
+def test_cate_pack_scales_follow_large_weights():
+    """Operand scales of the split arithmetic (csrc/dnag_common.h "Operand scales"): powers of two derived from the
+    weights so that scale * magnitude <= 60000 for every weight and every reachable activation."""
+    dims = CateDims()
+    model = mutils.create_model(score_config(dims, "cpu"))
+    sd = synthetic.cate_state_dict(dims, seed=0)
+    sd["final.linears.1.weight"][5, 7] = 300.0                                          # 256 * 300 > 65504
+    sd["graph_encoder.encoder_f.layers.2.feed_forward.feed_forward.w_1.weight"] *= 4000.0   # FFN hidden beyond 4094
+    sd["graph_encoder.encoder_f.norms.4.weight"] *= 900.0                               # |concat| up to 7200
+    model.load_state_dict(sd)
+    raw = model._pack_host(model._state_flat().contiguous()).numpy()
+    d, V, dff = 64, 7, 128
+    layer0 = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d
+    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d + 8
+    n_split, n_l16 = 1536 * 768 + 1536 * 1536, 12 * stride
+    hsc = raw[-16 - n_l16: -n_l16].astype(np.float64)
+    sa_c, sa1, sa2, sw3 = hsc[0], hsc[5], hsc[9], hsc[10]
+    sw0, sw1 = 1 / (hsc[4] * sa_c), 1 / (hsc[8] * sa1)
+    for v in (sa_c, sa1, sa2, sw0, sw1, sw3):
+        assert v > 0 and np.log2(v) == int(np.log2(v))                                   # powers of two
+    assert sw0 == 256 and sw3 == 256 and sw1 == 128 and sw1 * 300 <= 60000 < 2 * sw1 * 300
+    cbound = 8 * 900.0                                                                   # 8 max|gamma| + max|beta|
+    assert sa_c * cbound <= 60000 < 2 * sa_c * cbound and sa_c == 8
+    w0 = sd["final.linears.0.weight"].double().numpy()
+    h1b = max(1.0, (np.abs(w0).sum(1) * cbound + np.abs(sd["final.linears.0.bias"].double().numpy())).max())
+    assert sa1 * h1b <= 60000 * 1.001 and (sa1 == 16 or 2 * sa1 * h1b > 60000)
+    w1 = sd["final.linears.1.weight"].double().numpy()
+    h2b = max(1.0, (np.abs(w1).sum(1) * h1b + np.abs(sd["final.linears.1.bias"].double().numpy())).max())
+    assert sa2 * h2b <= 60000 * 1.001 and (sa2 == 16 or 2 * sa2 * h2b > 60000)
+    # the split-pair copy of final.linears.1 carries sw1 and reproduces the weights to 22 bits, 300 included
+    f1s = raw[-n_split - 16 - n_l16 + 1536 * 768: -16 - n_l16]
+    halves = f1s.view(np.float16).reshape(1536, 1536 // 8, 2, 8).astype(np.float64)
+    assert np.isfinite(halves).all()
+    rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 1536) / sw1
+    assert np.abs(rec - w1).max() <= 2.0 ** -21 * np.abs(w1).max() and abs(rec[5, 7] - 300.0) < 1e-4
+    # layer 2: the FFN hidden's scale follows the bound max_c (8 ||W1'_c||_2 + |b1'_c|), the W1 fragments their own scale
+    sc = raw[layer0 + 2 * stride + stride - 8: layer0 + 3 * stride].astype(np.float64)
+    W1 = sd["graph_encoder.encoder_f.layers.2.feed_forward.feed_forward.w_1.weight"].double().numpy()
+    b1 = sd["graph_encoder.encoder_f.layers.2.feed_forward.feed_forward.w_1.bias"].double().numpy()
+    fb = (8 * np.sqrt((W1 ** 2).sum(1)) + np.abs(b1)).max()                               # gamma = 1, beta = 0
+    sa_f2 = sc[4]
+    assert sa_f2 < 16 and sa_f2 * fb <= 60000 * 1.001 < 2 * sa_f2 * fb * 1.001
+    sw_1 = 1 / (16 * sc[3])
+    assert sw_1 * np.abs(W1).max() <= 60000 < 2 * sw_1 * np.abs(W1).max()
+    l16 = raw[-n_l16:]
+    assert np.isfinite(l16[2 * stride: 3 * stride - 8].view(np.float16).astype(np.float64)).all()
+    # non-finite weights are refused
+    sd["final.linears.0.weight"][0, 0] = float("nan")
+    model.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="not finite"):
+        model._pack_host(model._state_flat().contiguous())
 
 
 def test_predictor_pack_transposes():
@@ -175,12 +236,12 @@ def test_predictor_cate_pack_layout():
     D_, V, dff, L, F, Hd, R, RK, R2, R2P, RNP, hs, nz = 64, 9, 32, 2, 128, 256, 180, 192, 360, 384, 256, 512, 56
     al4 = lambda x: (x + 3) // 4 * 4
     layer0 = al4(D_ * V) + D_ + 4 * D_ * D_ + 4 * D_ + 4 * D_ * D_ + D_
-    stride = 3 * D_ * D_ + 3 * D_ + D_ * D_ + D_ + dff * D_ + dff + D_ * dff + D_ + 2 * D_
+    stride = 3 * D_ * D_ + 3 * D_ + D_ * D_ + D_ + dff * D_ + dff + D_ * dff + D_ + 2 * D_ + 8    # + operand scales
     f0 = layer0 + L * stride
     assert np.array_equal(packed[f0: f0 + Hd * F], sdp["final.linears.0.weight"].numpy().ravel())
     tab_end = f0 + Hd * F + Hd + Hd * Hd + Hd + al4(V * Hd) + al4(V) + al4(20 * D_) + al4(D_ // 2)
     assert not packed[tab_end - al4(D_ // 2) - al4(20 * D_): tab_end - al4(D_ // 2)].any()      # no positional table
-    enc_total = tab_end + Hd * F + Hd * Hd + L * stride   # split-pair / fp16-fragment copies (unused by this surrogate)
+    enc_total = tab_end + Hd * F + Hd * Hd + 16 + L * stride   # split-pair copies, head scales (unused by this surrogate), fp16 fragments
     # backward operands of layer 1: Wo^T and W2^T, fragment-major
     per_layer = 32 * 2 * 3 * D_ + 32 * 2 * D_ + 32 * 2 * dff + 32 * D_      # frag_floats(rows, K) = ceil(rows/32)*32*K
     b1 = enc_total + per_layer
