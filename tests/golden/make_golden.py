@@ -74,7 +74,7 @@ def main():
     import sde_lib                              # reference
     import sampling                             # reference
     import models.utils as mutils               # reference
-    from models import cate, digcn_meta         # noqa: F401  (registers the models)
+    from models import cate, digcn_meta         # registers the models
     import datasets_nas                         # reference
 
     out = {}
@@ -153,13 +153,24 @@ def main():
 
     # ------------------------------------------------------------------ D/E: sampler trajectories
     def run_sampler(tag, *, sde_N, n_run, B, guided, mask, preset, tape_seed, beta_max=20.0,
-                    classifier_scale=10000.0, full_record=True):
+                    classifier_scale=10000.0, full_record=True, double=False, extra=None):
         sde = sde_lib.VPSDE(beta_min=0.1, beta_max=beta_max, N=sde_N)
         cfg = score_config(nb)
         sdm = synthetic.cate_state_dict(nb, seed=0, preset=preset)
         score_model = mutils.create_model(cfg)
         score_model.load_state_dict(sdm, strict=True)
         tape = synthetic.noise_tape(n_run, (B, 8, 7), tape_seed)
+        if double:
+            # The same run in fp64: the reference's own modules cast to double, the same fp32 inputs (weights, tape,
+            # schedule tables, time embedding -- get_timestep_embedding builds it in fp32 by construction,
+            # cate.py:363-374, so only its result is cast).  Tie-breaker for trajectories whose fp32 rounding noise is
+            # amplified by the dynamics ("Hard parts" (iv)).
+            score_model.double()
+            clf.double()
+            tape = {k: v.double() for k, v in tape.items()}
+            orig_te = (cate.get_timestep_embedding, digcn_meta.get_timestep_embedding)
+            cate.get_timestep_embedding = lambda *a, **k: orig_te[0](*a, **k).double()
+            digcn_meta.get_timestep_embedding = lambda *a, **k: orig_te[1](*a, **k).double()
         queue = []
         for i in range(n_run):
             queue += [tape["corrector"][i], tape["predictor"][i]]
@@ -220,10 +231,11 @@ def main():
             fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), datasets_nas.get_data_inverse_scaler(cfg), 1e-3,
                                           conditional=guided, data_name="cifar10", num_sample=20)
             try:
+                mk, tk = (mask.double(), task.double()) if double else (mask, task)
                 if guided:
-                    final = fn(score_model, mask, clf, classifier_scale=classifier_scale, task=task)
+                    final = fn(score_model, mk, clf, classifier_scale=classifier_scale, task=tk)
                 else:
-                    final = fn(score_model, mask.unsqueeze(0))[0]
+                    final = fn(score_model, mk.unsqueeze(0))[0]
             except Stop:
                 pass
         finally:
@@ -232,7 +244,13 @@ def main():
             sampling.LangevinCorrector.update_fn = orig_c
             sampling.ReverseDiffusionPredictor.update_fn = orig_p
             clf.sample_state = False
+            if double:
+                clf.float()
+                cate.get_timestep_embedding, digcn_meta.get_timestep_embedding = orig_te
         assert real_N == sde_N
+        if double:
+            assert final.dtype == torch.float64
+            return final
         n_done = len(calls["pred"])
         arrs = dict(seed=0, preset=preset, tape_seed=tape_seed, sde_N=sde_N, beta_max=beta_max, n_run=n_done, B=B,
                     guided=int(guided), classifier_scale=classifier_scale, mask=mask, snr=0.16, eps=1e-3)
@@ -250,6 +268,8 @@ def main():
             arrs["x_mean_last"] = calls["pred"][-1][1]
         if final is not None:
             arrs["final"] = final
+        if extra:
+            arrs.update(extra)
         save(tag, **arrs)
 
     # random-init weights, real schedule (N=1000), first steps: per-step teacher-forced parity
@@ -267,9 +287,14 @@ def main():
 
     # decision margins: B=64 complete guided trajectories on three tapes; the test compares the discretised
     # architectures bit for bit and reports how far the final states sit from the 0.5 threshold
+    # Each run is captured twice, in the reference's fp32 and with its modules cast to fp64 (`final64`): these
+    # trajectories amplify rounding noise (a 1e-6 relative change of x0 moves the end state by 1e-5 .. 1e-2), so the
+    # fp32 reference is itself only one sample of that noise; the fp64 run says which entries fp32 can decide at all.
     for k, tape_seed in enumerate((31, 32, 33)):
-        run_sampler(f"pc_guided_nb201_contractive_margin{k}", sde_N=100, n_run=100, B=64, guided=True, mask=closure,
-                    preset="contractive", tape_seed=tape_seed, classifier_scale=100.0, full_record=False)
+        kw = dict(sde_N=100, n_run=100, B=64, guided=True, mask=closure, preset="contractive", tape_seed=tape_seed,
+                  classifier_scale=100.0, full_record=False)
+        f64 = run_sampler(f"pc_guided_nb201_contractive_margin{k}", double=True, **kw)
+        run_sampler(f"pc_guided_nb201_contractive_margin{k}", extra={"final64": f64}, **kw)
 
     for k, v in out.items():
         print(f"{k}.npz  {v/1024:.1f} KiB")

@@ -73,8 +73,10 @@ def test_encoder_weights_and_norm_affine_beyond_the_fixed_scales():
     X, t, m = _inputs(24, 22)
     out, concat, (ref, ref_concat) = _run(sd, X, t, m)
     assert float(ref_concat.abs().max()) > 4094.0
-    close(concat, ref_concat, 5e-6, "concat")
-    close(out, ref, 5e-6, "out")
+    # this network is 4 x worse conditioned than an ordinary one (the oracle's own fp32 concat is 1.6e-6 of the max away
+    # from its fp64 evaluation, 3.8e-7 on the unmodified weights), hence 2e-5 where the ordinary tests use 5e-6
+    close(concat, ref_concat, 2e-5, "concat")
+    close(out, ref, 2e-5, "out")
 
 
 def test_surrogate_weights_beyond_the_fixed_scale():
