@@ -227,29 +227,34 @@ def test_pc_full_n1000_guided_contractive():
     close(final, g["final"], 1e-3, "final")      # 2000 free-running evaluations: fp32 order differences compound
 
 
-@pytest.mark.parametrize("k", [0, 1, 2])
-def test_pc_full_trajectory_decision_margin(k):
+def test_pc_full_trajectory_decision_margin():
     """B=64 complete guided trajectories on three tapes (how close do final states sit to the 0.5
-    threshold, could 22-bit products flip a bit?).  These trajectories amplify rounding noise -- the reference's own
-    fp32 run ends up to 0.45 % (tape 31: one flipped bit) away from the same reference modules run in fp64 (`final64`,
-    tests/golden/make_golden.py) -- so the fp32 reference is one sample of that noise, not the truth.  Checked against
-    the fp64 run: (i) our end state is no further from it than 16 x the reference's own fp32 run is; (ii) every entry
-    the reference's fp32 arithmetic can decide (distance to the threshold > 8 x the reference's largest fp32 error)
-    discretises identically; the entries it cannot decide are counted and reported."""
-    g = golden(f"pc_guided_nb201_contractive_margin{k}")
-    final, _ = run_sampler(g, True, record=False)
-    got, ref32, ref64 = final.cpu().numpy().astype(np.float64), g["final"].astype(np.float64), g["final64"]
-    e_ref, e_our = np.abs(ref32 - ref64).max(), np.abs(got - ref64).max()
-    margin = np.abs(ref64 - 0.5)
-    decidable = margin > 8.0 * e_ref
-    flips_our = (got >= 0.5) != (ref64 >= 0.5)
-    flips_ref = (ref32 >= 0.5) != (ref64 >= 0.5)
-    print(f"margin{k}: |x| <= {np.abs(ref64).max():.4g}; max error vs fp64: reference fp32 {e_ref:.3g}, this path {e_our:.3g}; "
-          f"min margin {margin.min():.3g}; entries fp32 cannot decide {int((~decidable).sum())} of {margin.size} "
-          f"(flipped there: reference {int(flips_ref.sum())}, this path {int(flips_our.sum())})")
-    assert np.isfinite(got).all()
-    assert e_our <= 16.0 * e_ref, f"end state {e_our:.3g} from the fp64 run, the reference's fp32 run only {e_ref:.3g}"
-    assert not flips_our[decidable].any(), "a decidable entry discretises differently"
+    threshold, could 22-bit products flip a bit?).  These trajectories amplify rounding noise by 1e2 .. 1e5: the
+    reference's own fp32 runs end 4.5e-3 / 7.6e-6 / 1.3e-4 of max|x| away from the same reference modules run in fp64
+    (`final64`, tests/golden/make_golden.py), with one flipped bit on the first tape -- the fp32 reference is one
+    sample of that noise, not the truth, and its size on one tape says little about the next.  So the three tapes are
+    pooled: rho = the reference's largest relative fp32 error.  Checked against the fp64 runs: (i) no end state of this
+    path is further from them than 4 rho max|x|; (ii) every entry further than 8 rho max|x| from the threshold
+    discretises identically; the entries fp32 cannot decide are counted and reported with both paths' flips."""
+    gs = [golden(f"pc_guided_nb201_contractive_margin{k}") for k in range(3)]
+    rho = max(np.abs(g["final"].astype(np.float64) - g["final64"]).max() / np.abs(g["final64"]).max() for g in gs)
+    assert 1e-3 < rho < 1e-2          # the fixtures' own noise level (4.5e-3)
+    for k, g in enumerate(gs):
+        final, _ = run_sampler(g, True, record=False)
+        got, ref32, ref64 = final.cpu().numpy().astype(np.float64), g["final"].astype(np.float64), g["final64"]
+        xmax = np.abs(ref64).max()
+        e_ref, e_our = np.abs(ref32 - ref64).max(), np.abs(got - ref64).max()
+        margin = np.abs(ref64 - 0.5)
+        decidable = margin > 8.0 * rho * xmax
+        flips_our = (got >= 0.5) != (ref64 >= 0.5)
+        flips_ref = (ref32 >= 0.5) != (ref64 >= 0.5)
+        print(f"margin{k}: max|x| {xmax:.4g}; max error vs fp64: reference fp32 {e_ref:.3g} ({e_ref / xmax:.2g}), this path {e_our:.3g} "
+              f"({e_our / xmax:.2g}); min margin {margin.min():.3g}; entries fp32 cannot decide {int((~decidable).sum())} of {margin.size} "
+              f"(flipped: reference {int(flips_ref.sum())}, this path {int(flips_our.sum())})")
+        assert np.isfinite(got).all()
+        assert e_our <= 4.0 * rho * xmax, f"tape {k}: end state {e_our:.3g} from the fp64 run; pooled reference noise {rho * xmax:.3g}"
+        assert decidable.mean() > 0.85
+        assert not flips_our[decidable].any(), f"tape {k}: a decidable entry discretises differently"
 
 
 def test_unconditional_b256_step_matches_oracle():
