@@ -12,7 +12,7 @@ run() {   # run <seconds> <log> <cmd...>
 }
 for step in "$@"; do
 case $step in
-  new)    run 400 new_tests.log python -u -m pytest tests/test_gpu_range.py tests/test_gpu_shard.py tests/wip_no_alloc.py -v -s -m gpu --timeout 120 --timeout-method thread; tail -40 gpurun_out/new_tests.log ;;
+  new)    run 400 new_tests.log python -u -m pytest tests/test_gpu_range.py tests/test_gpu_shard.py tests/test_zz_no_alloc.py -v -s -m gpu --timeout 120 --timeout-method thread; tail -40 gpurun_out/new_tests.log ;;
   suite)  run 900 gpu_tests.log python -u -m pytest tests -m gpu -x -v --timeout 120 --timeout-method thread; tail -15 gpurun_out/gpu_tests.log ;;
   bench)  run 300 bench_default.log python bench.py; tail -1 gpurun_out/bench_default.log ;;
   train)  run 200 bench_train.log python bench.py --workload train; tail -1 gpurun_out/bench_train.log ;;
