@@ -28,6 +28,8 @@ struct CateLayout {
     size_t layer0, layer_stride;
     size_t l_wqkv, l_bqkv, l_wo, l_bo, l_w1, l_b1, l_w2, l_b2, l_ong, l_onb;  // relative to a layer base
     size_t l_sc;                  // per layer: 8 power-of-two scale factors of the split arithmetic (ENC_SC_*)
+    size_t l_vec;                 // per layer: contiguous copy bqkv' [3d] | bo [d] | b1' [dff] | b2 [d] | on_g [d] | on_b [d] (ENC_VEC_*),
+                                  // what encoder8_kernel stages into LDS with one 16-byte load per thread
     size_t f0_w, f0_b, f1_w, f1_b, f2_w, f2_b;  // final.linears.{0,1,2}
     size_t pe, freq;              // [N][d], [d/2]
     size_t f0_s, f1_s;            // final.linears.{0,1} weights as split-pair fp16 rows (dnag_gemm16.hip.h), same sizes
@@ -63,6 +65,7 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
     y.l_ong = l; l += d;
     y.l_onb = l; l += d;
     y.l_sc = l; l += 8;
+    y.l_vec = l; l += 3 * d + d + align4(dff) + d + d + d;
     y.layer_stride = l;
     o += l * y.L;
     const size_t F = y.F, Hd = y.Hd;

@@ -13,6 +13,7 @@
 
 #include "dnag_common.h"
 #include "dnag_encoder.hip.h"
+#include "dnag_encoder8.hip.h"
 #include "dnag_head.hip.h"
 #include "dnag_gemm16.hip.h"
 #include "dnag_predictor.hip.h"
@@ -196,6 +197,13 @@ static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *
         cbound = fmaxf(cbound, sqrtf((float)d) * amax_of(s + o, d) + amax_of(s + o + d, d));
         memcpy(LP + y.l_ong, s + o, d * sizeof(float)); o += d;
         memcpy(LP + y.l_onb, s + o, d * sizeof(float)); o += d;
+        float *vec = LP + y.l_vec;     // contiguous copy of the layer's vectors
+        memcpy(vec, LP + y.l_bqkv, 3 * d * sizeof(float)); vec += 3 * d;
+        memcpy(vec, LP + y.l_bo, d * sizeof(float)); vec += d;
+        memcpy(vec, LP + y.l_b1, dff * sizeof(float)); vec += align4(dff);
+        memcpy(vec, LP + y.l_b2, d * sizeof(float)); vec += d;
+        memcpy(vec, LP + y.l_ong, d * sizeof(float)); vec += d;
+        memcpy(vec, LP + y.l_onb, d * sizeof(float));
     }
     take(y.f0_w, Hd * F); take(y.f0_b, Hd);
     take(y.f1_w, Hd * Hd); take(y.f1_b, Hd);
@@ -628,6 +636,16 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
 
 static int launch_encoder(const dnag_cate_dims &c, const CateLayout &lay, const float *P, const float *x, const float *temb,
                           int tstride, const float *mask, int mstride, float *concat, float *attn0, int batch, hipStream_t st) {
+    if (is_nb201(c) && attn0 == nullptr) {       // the sampling path: dnag_encoder8.hip.h
+        typedef Enc8Geom Ge;
+        const size_t lds = Ge::lds_floats * sizeof(float);
+        auto kern = encoder8_kernel<7>;
+        static LdsAttr attr;
+        if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
+        hipLaunchKernelGGL(kern, dim3((batch + Ge::G - 1) / Ge::G), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, batch);
+        LAUNCH_CHECK();
+        return 0;
+    }
     if (is_nb201(c)) return launch_encoder_t<8, 7, 8>(lay, P, x, temb, tstride, mask, mstride, concat, attn0, batch, st);
     return launch_encoder_t<20, 9, 3>(lay, P, x, temb, tstride, mask, mstride, concat, attn0, batch, st);
 }

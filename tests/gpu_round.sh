@@ -18,7 +18,7 @@ case $step in
   train)  run 200 bench_train.log python bench.py --workload train; tail -1 gpurun_out/bench_train.log ;;
   ofa)    run 300 bench_ofa.log python bench.py --workload ofa --no-cpu-baseline; tail -1 gpurun_out/bench_ofa.log ;;
   prof)   cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-          run 300 prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
+          run 300 prof.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o bench -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra
           tail -1 gpurun_out/prof.log ;;
   profofa) run 300 prof_ofa.log rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ofa -o ofa -- python3 bench.py --workload ofa --steps 1 --warmup 0 --sde-steps 100 --no-cpu-baseline
           tail -1 gpurun_out/prof_ofa.log ;;

@@ -86,7 +86,7 @@ def test_cate_pack_folds_layernorm_into_linear():
     # layout constants restated from csrc/dnag_common.h
     d, V, dff = 64, 7, 128
     layer0 = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d
-    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d + 8     # ... + the 8 operand scales
+    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d + 8 + (7 * d + dff)   # + scales + vector copy
     rs = np.random.RandomState(0)
     h = rs.standard_normal((5, d))
     for l in (0, 7):
@@ -121,7 +121,7 @@ def test_cate_pack_folds_layernorm_into_linear():
     assert hsc[0] == 16.0 and hsc[4] == 1.0 / 4096 and hsc[5] == 16.0
     assert list(hsc[8:12]) == [1.0 / 4096, 16.0, 256.0, 1.0 / 4096]
     for l in range(12):
-        sc = raw_all[layer0 + l * stride + stride - 8: layer0 + (l + 1) * stride]
+        sc = raw_all[layer0 + l * stride + stride - 8 - 576: layer0 + (l + 1) * stride - 576]
         assert list(sc[:6]) == [1.0 / 4096, 16.0, 1.0 / 4096, 1.0 / 4096, 16.0, 1.0 / 4096], (l, sc)
     halves = raw[: 1536 * 768].view(np.float16).reshape(1536, 768 // 8, 2, 8).astype(np.float64)
     w0 = sd["final.linears.0.weight"].double().numpy()
@@ -156,7 +156,7 @@ def test_cate_pack_scales_follow_large_weights():
     raw = model._pack_host(model._state_flat().contiguous()).numpy()
     d, V, dff = 64, 7, 128
     layer0 = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d
-    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d + 8
+    stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d + 8 + (7 * d + dff)
     n_split, n_l16 = 1536 * 768 + 1536 * 1536, 12 * stride
     hsc = raw[-16 - n_l16: -n_l16].astype(np.float64)
     sa_c, sa1, sa2, sw3 = hsc[0], hsc[5], hsc[9], hsc[10]
@@ -179,7 +179,7 @@ def test_cate_pack_scales_follow_large_weights():
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 1536) / sw1
     assert np.abs(rec - w1).max() <= 2.0 ** -21 * np.abs(w1).max() and abs(rec[5, 7] - 300.0) < 1e-4
     # layer 2: the FFN hidden's scale follows the bound max_c (8 ||W1'_c||_2 + |b1'_c|), the W1 fragments their own scale
-    sc = raw[layer0 + 2 * stride + stride - 8: layer0 + 3 * stride].astype(np.float64)
+    sc = raw[layer0 + 2 * stride + stride - 8 - 576: layer0 + 3 * stride - 576].astype(np.float64)
     W1 = sd["graph_encoder.encoder_f.layers.2.feed_forward.feed_forward.w_1.weight"].double().numpy()
     b1 = sd["graph_encoder.encoder_f.layers.2.feed_forward.feed_forward.w_1.bias"].double().numpy()
     fb = (8 * np.sqrt((W1 ** 2).sum(1)) + np.abs(b1)).max()                               # gamma = 1, beta = 0
@@ -188,7 +188,7 @@ def test_cate_pack_scales_follow_large_weights():
     sw_1 = 1 / (16 * sc[3])
     assert sw_1 * np.abs(W1).max() <= 60000 < 2 * sw_1 * np.abs(W1).max()
     l16 = raw[-n_l16:]
-    assert np.isfinite(l16[2 * stride: 3 * stride - 8].view(np.float16).astype(np.float64)).all()
+    assert np.isfinite(l16[2 * stride: 3 * stride - 8 - 576].view(np.float16).astype(np.float64)).all()
     # non-finite weights are refused
     sd["final.linears.0.weight"][0, 0] = float("nan")
     model.load_state_dict(sd)
@@ -236,7 +236,7 @@ def test_predictor_cate_pack_layout():
     D_, V, dff, L, F, Hd, R, RK, R2, R2P, RNP, hs, nz = 64, 9, 32, 2, 128, 256, 180, 192, 360, 384, 256, 512, 56
     al4 = lambda x: (x + 3) // 4 * 4
     layer0 = al4(D_ * V) + D_ + 4 * D_ * D_ + 4 * D_ + 4 * D_ * D_ + D_
-    stride = 3 * D_ * D_ + 3 * D_ + D_ * D_ + D_ + dff * D_ + dff + D_ * dff + D_ + 2 * D_ + 8    # + operand scales
+    stride = 3 * D_ * D_ + 3 * D_ + D_ * D_ + D_ + dff * D_ + dff + D_ * dff + D_ + 2 * D_ + 8 + (7 * D_ + dff)    # + operand scales + vector copy
     f0 = layer0 + L * stride
     assert np.array_equal(packed[f0: f0 + Hd * F], sdp["final.linears.0.weight"].numpy().ravel())
     tab_end = f0 + Hd * F + Hd + Hd * Hd + Hd + al4(V * Hd) + al4(V) + al4(20 * D_) + al4(D_ // 2)
