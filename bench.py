@@ -104,12 +104,11 @@ def cpu_baseline(seconds=12.0):
 
 
 def bench_train(a, emit=True):
-    """BASELINE configs[2]: NAS-Bench-201 score-network DSM training step (loss + gradient of every parameter,
-    dropout 0.1 with on-device Philox masks) at batch 1024 on one GPU.  A step = dnag_cate_dsm_step on resident
-    inputs (the optimiser is the caller's, losses.py:22-36).  Algorithmic FLOPs: 3 x 63.36 MFLOP per graph
-    (forward + data gradient + weight gradient)."""
-    import ctypes as C
-    from diffusionnag_amd import losses
+    """BASELINE configs[2]: NAS-Bench-201 score-network DSM training step at batch 1024 on one GPU: the reference's
+    whole step_fn (losses.py:204-227) -- time / noise draws, forward with dropout 0.1 (on-device Philox masks), loss,
+    backward (dnag_cate_dsm_step), then gradient clipping + Adam with warm-up + EMA (dnag_optim_step) -- on resident
+    inputs.  Algorithmic FLOPs: 3 x 63.36 MFLOP per graph (forward + data gradient + weight gradient)."""
+    from diffusionnag_amd import ema as ema_lib, losses
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     B = 1024 if a.batch_per_gpu == 4096 else a.batch_per_gpu
@@ -117,40 +116,41 @@ def bench_train(a, emit=True):
     dims = CateDims()
     model = mutils.create_model(score_config(dev, dims))
     model.load_state_dict(synthetic.cate_state_dict(dims, seed=0))
+    model.dropout_p = 0.1
     sde = sde_lib.VPSDE(0.1, 20.0, 1000)
     g = torch.Generator().manual_seed(0)
     ops = torch.randint(0, 7, (B, 8), generator=g)
     x = (torch.nn.functional.one_hot(ops, 7).float() * 2 - 1).to(dev)
-    t = (torch.rand(B, generator=g) * (1 - 1e-5) + 1e-5).to(dev)
-    z = torch.randn(B, 8, 7, generator=g).to(dev)
     mask = utils.nb201_adj().unsqueeze(0).repeat(B, 1, 1).to(dev)
-    lib = _lib.load()
-    dc = model.dims_c()
-    keep = torch.empty(lib.dnag_dropout_mask_bytes(C.byref(dc), B), dtype=torch.uint8, device=dev)
-
-    def step(i):
-        _lib.check(lib.dnag_dropout_fill(C.byref(dc), B, 0.1, i, keep.data_ptr(), _lib.current_stream(dev)), "dnag_dropout_fill")
-        return losses.dsm_step(model, sde, x, t, z, mask, reduce_mean=True, keep=keep, dropout_p=0.1)
-
+    # configs/tr_scorenet.py: Adam lr 2e-5, beta1 0.9, eps 1e-8, no weight decay, warm-up 1000 steps, grad_clip 1, EMA 0.9999
+    cfg = Cfg(optim=Cfg(optimizer="Adam", lr=2e-5, beta1=0.9, eps=1e-8, weight_decay=0.0, warmup=1000, grad_clip=1.0))
+    state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()), step=0,
+                 ema=ema_lib.ExponentialMovingAverage(model.parameters(), decay=0.9999))
+    step_fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True)
+    model.train()
+    batch = (x, mask, mask)
     for i in range(max(a.warmup, 3)):
-        loss, grads = step(i)
+        loss = step_fn(state, batch)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(steps):
-        loss, grads = step(100 + i)
+        loss = step_fn(state, batch)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     flop = 3 * 63.36e6 * B
-    line = {"metric": "DSM training steps/sec (forward + backward), NB201", "value": steps / dt, "unit": "steps/s", "n_gpus": 1,
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    line = {"metric": "DSM training steps/sec (forward + backward + optimiser), NB201", "value": steps / dt, "unit": "steps/s", "n_gpus": 1,
             "steps": steps, "warmup": max(a.warmup, 3), "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2]: NAS-Bench-201 score-network DSM training step (forward+backward), batch {B}, "
-                                   "VPSDE beta 0.1-20, dropout 0.1 (Philox masks on device), raw adjacency mask, random-init weights",
-                       "batch_per_gpu": B, "includes": "state_dict flatten + on-device weight packing + forward + loss + backward; "
-                                                      "optimizer step excluded (host side, as in the reference)"},
+            "config": {"workload": f"BASELINE configs[2]: NAS-Bench-201 score-network DSM training step, batch {B}, "
+                                   "VPSDE beta 0.1-20, dropout 0.1 (Philox masks on device), raw adjacency mask, random-init weights, "
+                                   "Adam lr 2e-5 with warm-up, grad_clip 1, EMA 0.9999",
+                       "batch_per_gpu": B, "includes": "the reference's step_fn: draws of t and z, on-device weight packing, forward, loss, "
+                                                      "backward, gradient clipping, Adam, EMA (one flat parameter buffer; no host sync)"},
             "graphs_per_s": B * steps / dt, "whole_step_tflops": flop * steps / dt / 1e12,
             "whole_step_frac_of_f32_mfma_peak": flop * steps / dt / 1e12 / PEAK_F32_MFMA_TFLOPS,
-            "loss": float(loss), "grads_finite": bool(torch.isfinite(grads).all())}
+            "loss": float(loss.detach()), "params_finite": bool(torch.isfinite(flat).all()),
+            "grad_norm_last": float(state["optimizer"].last_grad_norm)}
     if emit:
         print(json.dumps(line), flush=True)
     return line

@@ -32,7 +32,7 @@ EXPORTS = (
     "dnag_quantize", "dnag_timing_begin", "dnag_timing_read", "dnag_timing_end",
     "dnag_nb201_seen_reset", "dnag_nb201_validity",
     "dnag_train_workspace_bytes", "dnag_dropout_mask_bytes", "dnag_dropout_fill", "dnag_cate_dsm_step",
-    "dnag_pred_forward_grad_noalloc",
+    "dnag_pred_forward_grad_noalloc", "dnag_optim_workspace_bytes", "dnag_optim_args_bytes", "dnag_optim_step",
 )
 
 
@@ -86,6 +86,18 @@ class TrainArgsC(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
     ]
 
+
+class OptimArgsC(C.Structure):
+    _fields_ = [
+        ("n", C.c_size_t), ("flags", C.c_int32), ("params", _fp), ("grads", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp),
+        ("shadow", _fp), ("beta1", C.c_float), ("beta2", C.c_float), ("one_minus_beta1", C.c_float),
+        ("one_minus_beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float), ("step_size", C.c_float),
+        ("bc2_sqrt", C.c_float), ("grad_clip", C.c_float), ("ema_one_minus_decay", C.c_float), ("grad_norm_out", _fp),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
+OPTIM_ADAM, OPTIM_EMA = 1, 2
 
 _lib: Optional[C.CDLL] = None
 
@@ -158,6 +170,13 @@ def load() -> C.CDLL:
         raise ImportError(f"{LIB_PATH}: ABI version {lib.dnag_abi_version()} != 1; rebuild the library")
     lib.dnag_ofa_validity.restype = i32
     lib.dnag_ofa_validity.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.dnag_optim_workspace_bytes.restype = sz
+    lib.dnag_optim_args_bytes.restype = sz
+    lib.dnag_optim_step.restype = i32
+    lib.dnag_optim_step.argtypes = [C.POINTER(OptimArgsC)]
+    if lib.dnag_optim_args_bytes() != C.sizeof(OptimArgsC):
+        raise ImportError(f"{LIB_PATH}: dnag_optim_args is {lib.dnag_optim_args_bytes()} bytes, this binding has "
+                          f"{C.sizeof(OptimArgsC)}; rebuild the library")
     lib.dnag_pc_args_bytes.restype = sz
     lib.dnag_train_args_bytes.restype = sz
     if lib.dnag_pc_args_bytes() != C.sizeof(PcArgsC) or lib.dnag_train_args_bytes() != C.sizeof(TrainArgsC):

@@ -312,6 +312,16 @@ __device__ __forceinline__ float pow2_scale(float amax) {
     return ldexpf(1.0f, k);
 }
 
+// a * b rounded to fp32 and NOT fused into a following addition: hipcc contracts a product into its consumer by default
+// (-ffp-contract=fast), through __fmul_rn / __fadd_rn and through `#pragma clang fp contract(off)` alike (both tried:
+// the EMA update came out as one v_fma_f32, tests/micro/ema_dbg.py).  The empty asm hides the product from that pass.
+// Used where the reference's expression rounds after every operation (predictor / corrector updates, Adam, EMA).
+__device__ __forceinline__ float mul_rn(float a, float b) {
+    float r = a * b;
+    asm volatile("" : "+v"(r));
+    return r;
+}
+
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 

@@ -292,9 +292,9 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
                 if (a.cgrad != nullptr) {
                     const float cg = a.cgrad[e];
                     float w = a.cscale;
-                    if (a.wr_mode == 1) w = __fmul_rn(w, gratio[g]);                                        // MBV3 sampling.py:886
-                    else if (a.wr_mode == 2) w = __fmul_rn(w, __fdiv_rn(fabsf(score), fabsf(cg)));        // :890-891
-                    total = __fadd_rn(score, __fmul_rn(w, cg));                                            // sampling.py:505
+                    if (a.wr_mode == 1) w = mul_rn(w, gratio[g]);                                        // MBV3 sampling.py:886
+                    else if (a.wr_mode == 2) w = mul_rn(w, __fdiv_rn(fabsf(score), fabsf(cg)));        // :890-891
+                    total = __fadd_rn(score, mul_rn(w, cg));                                            // sampling.py:505
                 }
                 if (a.rec_score) a.rec_score[e] = score;
                 if (a.rec_total) a.rec_total[e] = total;
@@ -308,14 +308,14 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
                     if (a.pred_kind == DNAG_PREDICTOR_EULER_MARUYAMA) {
                         // drift = c x - diffusion^2 total ; x_mean = x + drift dt ; x = x_mean + diffusion sqrt(-dt) z
                         // (sampling.py:194-200, sde_lib.py:95-103; a VESDE has c = 0)
-                        const float drift = __fsub_rn(__fmul_rn(a.sqrt_alpha, xv), __fmul_rn(a.G2, total));
-                        xm = __fadd_rn(xv, __fmul_rn(drift, a.dt));
+                        const float drift = __fsub_rn(mul_rn(a.sqrt_alpha, xv), mul_rn(a.G2, total));
+                        xm = __fadd_rn(xv, mul_rn(drift, a.dt));
                     } else {
-                        const float f = __fsub_rn(__fmul_rn(a.sqrt_alpha, xv), xv);
-                        const float rev_f = __fsub_rn(f, __fmul_rn(a.G2, total));
+                        const float f = __fsub_rn(mul_rn(a.sqrt_alpha, xv), xv);
+                        const float rev_f = __fsub_rn(f, mul_rn(a.G2, total));
                         xm = __fsub_rn(xv, rev_f);
                     }
-                    const float xn = __fadd_rn(xm, __fmul_rn(a.G, noise));
+                    const float xn = __fadd_rn(xm, mul_rn(a.G, noise));
                     a.x_mean[e] = xm;
                     a.x[e] = xn;
                     if (a.rec_a) a.rec_a[e] = xm;
@@ -381,16 +381,16 @@ __global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
     const float grad_norm = block_sum_256(sg, sh) / (float)a.batch;
     const float noise_norm = block_sum_256(sn, sh) / (float)a.batch;
     // step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
-    const float ratio = __fdiv_rn(__fmul_rn(a.snr, noise_norm), grad_norm);
-    const float step = __fmul_rn(__fmul_rn(__fmul_rn(ratio, ratio), 2.0f), a.alpha);
-    const float nscale = sqrtf(__fmul_rn(step, 2.0f));
+    const float ratio = __fdiv_rn(mul_rn(a.snr, noise_norm), grad_norm);
+    const float step = mul_rn(mul_rn(mul_rn(ratio, ratio), 2.0f), a.alpha);
+    const float nscale = sqrtf(mul_rn(step, 2.0f));
     if (blockIdx.x == 0 && tid == 0 && a.rec_step) {
         a.rec_step[0] = grad_norm; a.rec_step[1] = noise_norm; a.rec_step[2] = step;
     }
     for (size_t e = (size_t)blockIdx.x * 256 + tid; e < a.nelem; e += (size_t)gridDim.x * 256) {
         const float noise = a.noise ? a.noise[e] : philox_normal(a.seed, a.stream_offset + e, a.draw);
-        const float xm = __fadd_rn(a.x[e], __fmul_rn(step, a.gbuf[e]));
-        const float xn = __fadd_rn(xm, __fmul_rn(nscale, noise));
+        const float xm = __fadd_rn(a.x[e], mul_rn(step, a.gbuf[e]));
+        const float xn = __fadd_rn(xm, mul_rn(nscale, noise));
         a.x[e] = xn;
         if (a.rec_x) a.rec_x[e] = xn;
     }
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
 // x0 = prior sample (sde_lib.py:190-191): copy of the caller's tensor, or Philox draw 0.
 __global__ void prior_kernel(float *x, const float *x0, size_t nelem, uint64_t seed, uint64_t stream_offset, float scale) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nelem; e += (size_t)gridDim.x * blockDim.x)
-        x[e] = x0 ? x0[e] : __fmul_rn(philox_normal(seed, stream_offset + e, 0u), scale);
+        x[e] = x0 ? x0[e] : mul_rn(philox_normal(seed, stream_offset + e, 0u), scale);
 }
 
 // out = (x_mean + 1) / 2  (datasets_nas.py:21-28)
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const float *__restrict
     const int tid = threadIdx.x, half = d / 2;
     const float lab = labels[blockIdx.x];
     for (int j = tid; j < d; j += 256) {
-        const float arg = __fmul_rn(lab, freq[j < half ? j : j - half]);
+        const float arg = mul_rn(lab, freq[j < half ? j : j - half]);
         e[j] = j < half ? sinf(arg) : cosf(arg);
     }
     __syncthreads();

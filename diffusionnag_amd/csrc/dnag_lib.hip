@@ -1304,6 +1304,31 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     return 0;
 }
 
+extern "C" size_t dnag_optim_workspace_bytes(void) { return OPTIM_BLOCKS * sizeof(double); }
+extern "C" size_t dnag_optim_args_bytes(void) { return sizeof(dnag_optim_args); }
+
+extern "C" int dnag_optim_step(const dnag_optim_args *p) {
+    if (!p) return fail(DNAG_E_ARG, "args is NULL");
+    if (p->n == 0) return 0;
+    const bool adam = p->flags & DNAG_OPTIM_ADAM, ema = p->flags & DNAG_OPTIM_EMA;
+    if (!adam && !ema) return fail(DNAG_E_ARG, "flags=%d selects neither DNAG_OPTIM_ADAM nor DNAG_OPTIM_EMA", p->flags);
+    if (!p->params || (adam && (!p->grads || !p->exp_avg || !p->exp_avg_sq)) || (ema && !p->shadow)) return fail(DNAG_E_ARG, "NULL pointer");
+    if (adam && (!(p->bc2_sqrt > 0.f) || !(p->eps >= 0.f) || !std::isfinite(p->step_size)))
+        return fail(DNAG_E_ARG, "bc2_sqrt=%g eps=%g step_size=%g", p->bc2_sqrt, p->eps, p->step_size);
+    hipStream_t st = (hipStream_t)p->stream;
+    const bool need_norm = adam && (p->grad_clip >= 0.f || p->grad_norm_out);
+    if (need_norm) {
+        if (!p->workspace || p->workspace_bytes < dnag_optim_workspace_bytes())
+            return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", p->workspace_bytes, dnag_optim_workspace_bytes());
+        hipLaunchKernelGGL(optim_sumsq_kernel, dim3(OPTIM_BLOCKS), dim3(256), 0, st, p->grads, p->n, (double *)p->workspace);
+        LAUNCH_CHECK();
+    }
+    const size_t nb = (p->n + 255) / 256;
+    hipLaunchKernelGGL(optim_update_kernel, dim3((unsigned)(nb < 2048 ? nb : 2048)), dim3(256), 0, st, *p, (const double *)p->workspace);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dnag_nb201_seen_reset(int32_t *first_seen, void *stream) {
     if (!first_seen) return fail(DNAG_E_ARG, "NULL pointer");
     hipLaunchKernelGGL(fill_i32_kernel, dim3(16), dim3(1024), 0, (hipStream_t)stream, first_seen, (size_t)NB201_NCODES, (int32_t)NB201_UNSEEN);

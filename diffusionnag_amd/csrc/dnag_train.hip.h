@@ -1069,3 +1069,64 @@ __global__ void dropout_fill_kernel(uint8_t *keep, size_t n, float p, uint64_t s
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Optimiser side of the step (include/dnag.h, dnag_optim_step): global gradient norm, clipping, Adam, EMA
+// ---------------------------------------------------------------------------------------------
+#define OPTIM_BLOCKS 256
+// partial[b] = sum of squares of the b-th contiguous chunk, accumulated in double in a fixed order
+__global__ __launch_bounds__(256) void optim_sumsq_kernel(const float *__restrict__ g, size_t n, double *__restrict__ partial) {
+    __shared__ double sh[256];
+    const size_t chunk = (n + OPTIM_BLOCKS - 1) / OPTIM_BLOCKS;
+    const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    double acc = 0.0;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)g[i] * (double)g[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sh[threadIdx.x] += sh[threadIdx.x + s2];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void optim_update_kernel(const dnag_optim_args a, const double *__restrict__ partial) {
+    float coef = 1.0f;
+    if ((a.flags & DNAG_OPTIM_ADAM) && (a.grad_clip >= 0.f || a.grad_norm_out)) {
+        // every block sums the partials in the same order: one value everywhere, no grid barrier
+        __shared__ double tot;
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int b = 0; b < OPTIM_BLOCKS; ++b) t += partial[b];
+            tot = t;
+        }
+        __syncthreads();
+        const float norm = (float)sqrt(tot);
+        if (a.grad_norm_out && blockIdx.x == 0 && threadIdx.x == 0) *a.grad_norm_out = norm;
+        if (a.grad_clip >= 0.f) {
+            coef = __fdiv_rn(a.grad_clip, __fadd_rn(norm, 1e-6f));      // clip_grad_norm_: max_norm / (total_norm + 1e-6)
+            coef = coef > 1.0f ? 1.0f : coef;                            // clamp(max=1.0); the gradient is always multiplied
+        }
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (size_t)gridDim.x * 256) {
+        float p = a.params[i];
+        if (a.flags & DNAG_OPTIM_ADAM) {
+            float g = mul_rn(a.grads[i], coef);
+            if (a.weight_decay != 0.f) g = __fadd_rn(g, mul_rn(a.weight_decay, p));              // grad.add(param, alpha=weight_decay)
+            float m = a.exp_avg[i], v = a.exp_avg_sq[i];
+            // operation orders of torch's CPU kernels (the goldens' source): lerp = fma(w, end - start, start) for w < 0.5,
+            // addcmul = self + (value * t1) * t2, addcdiv = self + (value * t1) / t2
+            m = __fmaf_rn(a.one_minus_beta1, __fsub_rn(g, m), m);                                   // exp_avg.lerp_(grad, 1 - beta1)
+            v = __fadd_rn(mul_rn(v, a.beta2), mul_rn(mul_rn(a.one_minus_beta2, g), g));    // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+            const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(v), a.bc2_sqrt), a.eps);             // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
+            p = __fadd_rn(p, __fdiv_rn(mul_rn(-a.step_size, m), denom));                         // param.addcdiv_(exp_avg, denom, value=-step_size)
+            a.exp_avg[i] = m;
+            a.exp_avg_sq[i] = v;
+            a.params[i] = p;
+        }
+        if (a.flags & DNAG_OPTIM_EMA) {
+            const float s = a.shadow[i];
+            a.shadow[i] = __fsub_rn(s, mul_rn(a.ema_one_minus_decay, __fsub_rn(s, p)));          // s_param.sub_(one_minus_decay * (s_param - param))
+        }
+    }
+}

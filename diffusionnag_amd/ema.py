@@ -1,11 +1,17 @@
-"""Host-side EMA of the parameters, the object ``step_fn`` keeps in ``state['ema']`` (reference
-``models/ema.py:4-85``: same constructor, methods, ``state_dict`` keys and decay warm-up).  The update runs
-as two multi-tensor (``torch._foreach``) launches over all ~200 parameter tensors instead of one small
-launch per tensor; it is plain PyTorch plumbing, not part of the HIP path."""
+"""EMA of the parameters, the object ``step_fn`` keeps in ``state['ema']`` (reference ``models/ema.py:4-85``: same
+constructor, methods, ``state_dict`` keys and decay warm-up).  The shadow parameters are views of one flat buffer; on
+the GPU the update is one pass of ``dnag_optim_step`` (``include/dnag.h``) with the reference's operation order
+(``s -= (1 - d) (s - p)``, no fused multiply-add: bit-identical to ``models/ema.py:39-42`` for the same parameters),
+either on its own (``update``) or folded into the optimiser's pass (``losses.FusedAdam.step(ema=...)``)."""
 
 from __future__ import annotations
 
+import ctypes as C
+
 import torch
+
+from . import _lib
+from .flat import chain_view, flatten_
 
 
 class ExponentialMovingAverage:
@@ -17,16 +23,37 @@ class ExponentialMovingAverage:
         self.shadow_params = [p.clone().detach() for p in parameters if p.requires_grad]
         self.collected_params = []
 
-    def update(self, parameters):
-        """shadow -= (1 - decay) (shadow - param), decay = min(decay, (1 + n) / (10 + n))  (ema.py:34-42)."""
+    def next_one_minus_decay(self) -> float:
+        """Advance ``num_updates`` and return ``1 - decay`` of this update, in Python doubles (ema.py:34-38)."""
         decay = self.decay
         if self.num_updates is not None:
             self.num_updates += 1
             decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
-        with torch.no_grad():
-            live = [p.detach() for p in parameters if p.requires_grad]
-            diff = torch._foreach_sub(self.shadow_params, live)
-            torch._foreach_mul_(diff, 1.0 - decay)          # same operation order as the reference: bit-identical
+        return 1.0 - decay
+
+    def flat_shadow(self, like=None) -> torch.Tensor:
+        """The shadow parameters as one flat buffer (re-seated as views of it on first use)."""
+        if like is not None and self.shadow_params and self.shadow_params[0].device != like[0].device:
+            self.shadow_params = [s.to(like[0].device) for s in self.shadow_params]
+        return flatten_(self.shadow_params)
+
+    def update(self, parameters):
+        """shadow -= (1 - decay) (shadow - param), decay = min(decay, (1 + n) / (10 + n))  (ema.py:24-42)."""
+        live = [p for p in parameters if p.requires_grad]
+        omd = self.next_one_minus_decay()
+        flat = chain_view([p.data for p in live])
+        if flat is not None and flat.is_cuda:
+            lib = _lib.load()
+            a = _lib.OptimArgsC()
+            a.n, a.flags = flat.numel(), _lib.OPTIM_EMA
+            a.params, a.shadow, a.ema_one_minus_decay = _lib.ptr(flat), _lib.ptr(self.flat_shadow(live)), omd
+            a.stream = _lib.current_stream(flat.device)
+            with torch.cuda.device(flat.device):
+                _lib.check(lib.dnag_optim_step(C.byref(a)), "dnag_optim_step")
+            return
+        with torch.no_grad():        # parameters that are not one flat device buffer (host-side use): multi-tensor plumbing
+            diff = torch._foreach_sub(self.shadow_params, [p.detach() for p in live])
+            torch._foreach_mul_(diff, omd)                  # same operation order as the reference: bit-identical
             torch._foreach_sub_(self.shadow_params, diff)
 
     def copy_to(self, parameters):

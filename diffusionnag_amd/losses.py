@@ -16,30 +16,129 @@ from typing import Dict, Optional
 
 import numpy as np
 import torch
-import torch.optim as optim
 
 from . import _lib, sde_lib
+from .flat import chain_view, flatten_
 from .cate import CATE, Workspace, positional_table, timestep_frequencies
 
 
+class FusedAdam:
+    """The ``torch.optim.Adam`` surface the reference's training code touches (``param_groups[...]['lr']``,
+    ``zero_grad``, ``step``, ``state_dict`` / ``load_state_dict`` in torch's format), on flat device buffers: one call
+    of ``dnag_optim_step`` (``include/dnag.h``) computes the global gradient norm, clips, applies Adam and -- when the
+    EMA object is handed over -- updates the shadow parameters.  The parameters are re-seated once as views of one flat
+    buffer (``flat.flatten_``), so ``model.parameters()`` and ``state_dict()`` keep working on the same memory.
+    The Python-double scalars of ``torch.optim.adam._single_tensor_adam`` (bias corrections, step size) are computed
+    here exactly as torch does and handed over rounded to fp32, as torch rounds them when they meet an fp32 tensor."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.params = [p for p in params if p.requires_grad]
+        self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)]
+        self.t = 0
+        self._m = self._v = self._ws = None
+        self.last_grad_norm = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.params:
+            p.grad = None
+
+    def _state(self, flat):
+        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
+            self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+            self._ws = torch.empty(_lib.load().dnag_optim_workspace_bytes() // 4, dtype=torch.float32, device=flat.device)
+            self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
+
+    def step(self, grad_clip: float = -1.0, ema=None):
+        lib = _lib.load()
+        flat = flatten_(self.params)
+        dev = _lib.require_device(flat)
+        grads = chain_view([p.grad for p in self.params])
+        if grads is None:      # gradients that did not come from the fused training step: gather them (plumbing)
+            grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in self.params])
+        self._state(flat)
+        g = self.param_groups[0]
+        beta1, beta2 = g['betas']
+        self.t += 1
+        bias_correction1 = 1 - beta1 ** self.t                 # torch/optim/adam.py, python floats
+        bias_correction2 = 1 - beta2 ** self.t
+        step_size = float(g['lr']) / bias_correction1
+        a = _lib.OptimArgsC()
+        a.n, a.flags = flat.numel(), _lib.OPTIM_ADAM
+        a.params, a.grads, a.exp_avg, a.exp_avg_sq = _lib.ptr(flat), _lib.ptr(grads.contiguous()), _lib.ptr(self._m), _lib.ptr(self._v)
+        a.beta1, a.beta2, a.one_minus_beta1, a.one_minus_beta2 = beta1, beta2, 1 - beta1, 1 - beta2
+        a.eps, a.weight_decay = g['eps'], g['weight_decay']
+        a.step_size, a.bc2_sqrt = step_size, bias_correction2 ** 0.5
+        a.grad_clip = float(grad_clip)
+        a.grad_norm_out = _lib.ptr(self.last_grad_norm)
+        if ema is not None:
+            a.flags |= _lib.OPTIM_EMA
+            a.shadow = _lib.ptr(ema.flat_shadow(self.params))
+            a.ema_one_minus_decay = ema.next_one_minus_decay()
+        a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel() * 4
+        a.stream = _lib.current_stream(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.dnag_optim_step(C.byref(a)), "dnag_optim_step")
+
+    # torch.optim.Adam's checkpoint format (reference utils.py:104-121 saves optimizer.state_dict())
+    def state_dict(self):
+        state, o = {}, 0
+        for i, p in enumerate(self.params):
+            n = p.numel()
+            if self._m is not None:
+                state[i] = dict(step=torch.tensor(float(self.t)), exp_avg=self._m[o:o + n].view(p.shape).clone(),
+                                exp_avg_sq=self._v[o:o + n].view(p.shape).clone())
+            o += n
+        grp = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        grp['params'] = list(range(len(self.params)))
+        return dict(state=state, param_groups=[grp])
+
+    def load_state_dict(self, sd):
+        grp = sd['param_groups'][0]
+        for k in ('lr', 'betas', 'eps', 'weight_decay'):
+            if k in grp:
+                self.param_groups[0][k] = grp[k] if k != 'betas' else tuple(grp[k])
+        st = sd['state']
+        if st:
+            flat = flatten_(self.params)
+            self._m = self._v = None
+            self._state(flat)
+            o = 0
+            for i, p in enumerate(self.params):
+                n = p.numel()
+                e = st.get(i, st.get(str(i)))
+                if e is not None:
+                    self._m[o:o + n].copy_(e['exp_avg'].reshape(-1))
+                    self._v[o:o + n].copy_(e['exp_avg_sq'].reshape(-1))
+                    self.t = int(float(e['step']))
+                o += n
+
+
 def get_optimizer(config, params):
-    """Reference ``losses.py:10-19``."""
+    """Reference ``losses.py:10-19``; the Adam it returns runs on the device in one fused launch chain (``FusedAdam``)."""
     if config.optim.optimizer == 'Adam':
-        return optim.Adam(params, lr=config.optim.lr, betas=(config.optim.beta1, 0.999), eps=config.optim.eps,
-                          weight_decay=config.optim.weight_decay)
+        return FusedAdam(params, lr=config.optim.lr, betas=(config.optim.beta1, 0.999), eps=config.optim.eps,
+                         weight_decay=config.optim.weight_decay)
     raise NotImplementedError(f'Optimizer {config.optim.optimizer} not supported yet!')
 
 
 def optimization_manager(config):
-    """Reference ``losses.py:22-36``: warm-up, gradient clipping, optimiser step (host side)."""
+    """Reference ``losses.py:22-36``: warm-up, gradient clipping, optimiser step.  With a ``FusedAdam`` the clipping is
+    part of the optimiser's launch chain; ``ema`` (an extension of the reference's signature, used by ``step_fn``)
+    folds the EMA update of ``models/ema.py:24-42`` into the same pass."""
 
-    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip):
+    def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip,
+                    ema=None):
         if warmup > 0:
             for g in optimizer.param_groups:
                 g['lr'] = lr * np.minimum(step / warmup, 1.0)
-        if grad_clip >= 0:
+        if isinstance(optimizer, FusedAdam):
+            optimizer.step(grad_clip=grad_clip, ema=ema)
+            return
+        if grad_clip >= 0:                      # a torch optimiser handed in by the caller: the reference's own lines
             torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
         optimizer.step()
+        if ema is not None:
+            ema.update(params)
 
     return optimize_fn
 
@@ -83,10 +182,11 @@ class _DsmStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         (flat,) = ctx.saved_tensors
+        g = flat * grad_out                      # one launch; the parameters' .grad become views of this buffer
         outs, o = [], 0
         for shp in ctx.shapes:
             n = int(np.prod(shp))
-            outs.append((flat[o:o + n] * grad_out).reshape(shp))
+            outs.append(g[o:o + n].view(shp))
             o += n
         return (None, None) + tuple(outs)
 
@@ -122,7 +222,9 @@ def dsm_step(model: CATE, sde, x, t, z, mask, *, reduce_mean=True, keep: Optiona
     if m.shape[1:] != (N, N) or m.shape[0] not in (1, B):
         raise ValueError(f"mask has shape {tuple(m.shape)}, expected [{B}|1, {N}, {N}]")
     params = [p for p in model.state_dict(keep_vars=True).values()]
-    flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
+    flat = chain_view([p.data for p in params])          # already one flat buffer once an optimiser step has run
+    if flat is None:
+        flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
     dc = model.dims_c()
     if flat.numel() != lib.dnag_cate_state_floats(C.byref(dc)):
         raise RuntimeError("state_dict size does not match the CATE layout")
@@ -228,9 +330,13 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
             optimizer.zero_grad()
             loss = loss_fn(model, batch)
             loss.backward()
-            optimize_fn(optimizer, model.parameters(), step=state['step'])
-            state['step'] += 1
-            state['ema'].update(model.parameters())
+            if isinstance(optimizer, FusedAdam) and hasattr(state['ema'], 'flat_shadow'):
+                optimize_fn(optimizer, model.parameters(), step=state['step'], ema=state['ema'])     # Adam + EMA in one pass
+                state['step'] += 1
+            else:
+                optimize_fn(optimizer, model.parameters(), step=state['step'])
+                state['step'] += 1
+                state['ema'].update(model.parameters())
         else:
             with torch.no_grad():
                 ema = state['ema']

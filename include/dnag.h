@@ -286,6 +286,44 @@ size_t dnag_dropout_mask_bytes(const dnag_cate_dims *d, int batch);
 int    dnag_dropout_fill(const dnag_cate_dims *d, int batch, float p, uint64_t seed, uint8_t *keep, void *stream);
 int    dnag_cate_dsm_step(const dnag_train_args *args);
 
+/* ---- optimiser side of the training step --------------------------------------------
+ * Replaces, on flat fp32 buffers in state_dict() order, what follows loss.backward() in step_fn (losses.py:222-226):
+ *   optimization_manager(...).optimize_fn (losses.py:22-36): warm-up learning rate, torch.nn.utils.clip_grad_norm_ over
+ *   ALL parameters (total L2 norm, coefficient min(1, max_norm / (norm + 1e-6))), torch.optim.Adam.step (get_optimizer,
+ *   losses.py:10-19: betas (beta1, 0.999), eps, weight_decay added to the gradient; no amsgrad), then
+ *   ExponentialMovingAverage.update (models/ema.py:24-42): shadow -= (1 - decay) (shadow - param), with this operation
+ *   order and no fused multiply-add, so that the shadow is bit-identical to the reference's given the same parameters.
+ * Two launches: a fixed-order sum of squares (per-block partials in the workspace), then one element-wise pass in which
+ * every block re-reduces the partials in the same order (no atomics: the result does not depend on the launch).
+ * The scalars that the reference computes in Python doubles are computed by the host mirror the same way and handed
+ * over as the fp32 values torch would round them to (diffusionnag_amd/losses.py FusedAdam):
+ *   step_size = lr_t / (1 - beta1^t), bc2_sqrt = sqrt(1 - beta2^t), lr_t = lr min(step / warmup, 1), t = Adam step count.
+ * flags: DNAG_OPTIM_ADAM and / or DNAG_OPTIM_EMA.  grads are read only (the reference scales .grad in place when it
+ * clips; nothing reads it afterwards).  grad_norm_out (may be NULL) receives the total norm before clipping. */
+#define DNAG_OPTIM_ADAM 1
+#define DNAG_OPTIM_EMA  2
+typedef struct dnag_optim_args {
+    size_t n;                          /* parameters (dnag_cate_state_floats for the score network) */
+    int32_t flags;
+    float *params;                     /* device [n], updated in place */
+    const float *grads;                /* device [n] */
+    float *exp_avg, *exp_avg_sq;       /* device [n] Adam moments, updated in place */
+    float *shadow;                     /* device [n] EMA shadow parameters (DNAG_OPTIM_EMA) */
+    float beta1, beta2;                /* as torch rounds the python floats to fp32 */
+    float one_minus_beta1, one_minus_beta2;
+    float eps, weight_decay;
+    float step_size, bc2_sqrt;
+    float grad_clip;                   /* max_norm; negative: no clipping (losses.py:32) */
+    float ema_one_minus_decay;         /* 1 - min(decay, (1 + n) / (10 + n)) in double, rounded to fp32 (ema.py:34-38) */
+    float *grad_norm_out;              /* device [1] or NULL */
+    void *workspace;                   /* dnag_optim_workspace_bytes() */
+    size_t workspace_bytes;
+    void *stream;
+} dnag_optim_args;
+size_t dnag_optim_workspace_bytes(void);
+size_t dnag_optim_args_bytes(void);
+int    dnag_optim_step(const dnag_optim_args *args);
+
 /* ---- exit of a sampling round, NAS-Bench-201 ---------------------------------
  * Replaces quantize (utils.py:244-262) + is_valid_NAS201_x (analysis/arch_functions.py:284-329) + the argmax
  * decode (:209-216) that BasicArchMetricsMeta.compute_validity (:95-118) runs per sample on the host, and the
