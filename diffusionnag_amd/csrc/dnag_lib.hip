@@ -16,6 +16,7 @@
 #include "dnag_encoder8.hip.h"
 #include "dnag_head.hip.h"
 #include "dnag_gemm16.hip.h"
+#include "dnag_gemm_dma.hip.h"
 #include "dnag_predictor.hip.h"
 #include "dnag_predcate.hip.h"
 #include "dnag_train.hip.h"
@@ -559,6 +560,7 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
         }
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev0[slot], st));
+#ifdef DNAG_OLD_GEMM   // debug builds: the 32x32x16 register-staged kernel of round 1 (dnag_gemm16.hip.h), for A/B runs
     // split-arithmetic fp16 MFMA GEMMs (dnag_gemm16.hip.h): final.linears.0 (K = F) reads the encoder's split-pair
     // concat and writes split-pair rows; final.linears.1 (K = 2F, the timed one) writes fp32 for the exit kernel
     typedef SplitGeom Ge;
@@ -581,6 +583,27 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
     } else {
         hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr, nofa);
     }
+#else
+    // split-arithmetic fp16 MFMA GEMMs (dnag_gemm_dma.hip.h): final.linears.0 (K = F) reads the encoder's split-pair
+    // concat and writes split-pair rows; final.linears.1 (K = 2F, the timed one) applies final.linears.2 in its epilogue
+    typedef DmaGeom Ge;
+    if (M % Ge::BM || Nout % Ge::BN || K % Ge::BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
+    const int grid = (int)(M / Ge::BM) * (Nout / Ge::BN);
+    auto k7 = gemm_dma_kernel<ACT_ELU, false, 7>;      // final.linears.1 + final.linears.2 fused, NAS-Bench-201
+    auto k9 = gemm_dma_kernel<ACT_ELU, false, 9>;      // same, OFA
+    auto k0 = gemm_dma_kernel<ACT_ELU, true, 0>;
+    static LdsAttr a7, a9, a0;
+    if (int rc = ensure_lds(a7, reinterpret_cast<const void *>(k7), Ge::lds_bytes)) return rc;
+    if (int rc = ensure_lds(a9, reinterpret_cast<const void *>(k9), Ge::lds_bytes)) return rc;
+    if (int rc = ensure_lds(a0, reinterpret_cast<const void *>(k0), Ge::lds_bytes)) return rc;
+    if (timed) {
+        if (V != 7 && V != 9) return fail(DNAG_E_ARG, "fused head GEMM is built for 7 or 9 output columns, got %d", V);
+        // C receives the partial sums [Nout / 256][M][V] of final.linears.2
+        hipLaunchKernelGGL(V == 7 ? k7 : k9, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, (float *)nullptr, (int)M, Nout, K, W3, C, sc);
+    } else {
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr, sc);
+    }
+#endif
     LAUNCH_CHECK();
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
     return 0;
