@@ -1,4 +1,4 @@
-// Head MLP GEMMs of the sampling path, second generation (final.linears.0 and final.linears.1 + .2, cate.py:55-73):
+// Head MLP GEMMs of the sampling path, third generation (final.linears.0 and final.linears.1 + .2, cate.py:55-73):
 // the split arithmetic and the split-pair operand rows of dnag_gemm16.hip.h, with
 //   * v_mfma_f32_16x16x32_f16 instead of 32x32x16: on this chip the matrix cores are power limited, and the 16x16x32 form
 //     sustains 1.12-1.13 x the rate on random operands (tests/micro/mfma_shapes.hip: 1844 against 1632 TFLOP/s);
@@ -8,8 +8,19 @@
 //     destination is lane-linear by construction) and to the fragment reads.  Within a staged row of 32 k the slots are
 //     planar: p = kg for the fp16 hi half of k group kg (8 values), p = 4 + kg for its lo half, so lane (row l & 15,
 //     k group l >> 4) of a 16x16x32 fragment reads one slot for hi and one for lo; both are conflict free;
-//   * two LDS buffers of 64 KB, the DMA of tile t+1 in flight under the 96 MFMAs per wave of tile t, one barrier per tile.
-// Block tile 256 x 256 x 32, 8 waves (2 x 4) of 128 x 64 = 8 x 4 MFMA tiles, one workgroup per CU.
+//   * a phased main loop.  A k tile (32 k) is staged as four half tiles of 128 rows x 128 B = 16 KB (A rows 0-127, B rows
+//     0-127, B rows 128-255, A rows 128-255), two k tiles of them in LDS (128 KB).  A wave owns a 64 x 32 piece of each
+//     quadrant (A half, B half) of the 256 x 256 block tile and works through the quadrants in four phases per k tile;
+//     a phase is a load segment (fragment reads of the half tile that is new to the phase, two DMA pieces, a counted
+//     vmcnt), a barrier, a compute segment (24 MFMAs), a barrier.  The two waves of a SIMD (w and w + 4) run one segment
+//     apart, so in every segment one of them feeds the matrix cores while the other reads LDS and issues DMA.  Every
+//     phase stages one half tile (16 pieces, 2 per wave), four phases = one k tile of time before it is read; the
+//     DMA stays in flight across the raw s_barriers and is retired by vmcnt(8) in the load segment of the phase BEFORE
+//     the one that reads it (the barriers between order the other waves' pieces); a half tile's slot is restaged two
+//     or three phases after its last read.  Measured on the way here (same box, final.linears.1 at B = 4096): with the
+//     DMA removed the loop ran at 93 % MFMA issue (3292 cycles per k tile of 3072), with it 4200-4900, whether the 64
+//     pieces of a k tile were issued as a burst, spread between the MFMAs, or staggered between the waves of a SIMD.
+// Block tile 256 x 256 x 32, 8 waves (2 x 4), one workgroup per CU.
 // Included by dnag_lib.hip.
 #pragma once
 #include "dnag_common.h"
@@ -21,7 +32,8 @@ __device__ __forceinline__ f32x4 mfma16x(h8 a, h8 b, f32x4 c) { return __builtin
 struct DmaGeom {
     static constexpr int BM = 256, BN = 256, BK = 32, T = 512;
     static constexpr int ROWW = 32;                                   // dwords per staged row (32 k: 16 of hi, 16 of lo)
-    static constexpr size_t lds_bytes = 2 * (size_t)(BM + BN) * ROWW * sizeof(float);
+    static constexpr int HALF = 128 * ROWW;                           // floats per half tile
+    static constexpr size_t lds_bytes = 2 * 4 * (size_t)HALF * sizeof(float);
 };
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -31,21 +43,21 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 // (dnag_common.h HEAD_SC_F0 / _F1).  OUT_SPLIT: C is written as split-pair rows scaled by sc[1] (final.linears.0).
 // FUSE_V > 0: operands swapped (lane <-> batch row) and final.linears.2 (W3 [FUSE_V][Nout]) applied to the ELU output in
 // registers on the same MFMAs; parts [Nout / 256][M][FUSE_V] receives this block's partial sums (dnag_gemm16.hip.h).
+// M and Nout multiples of 256, K a multiple of 32.
 template <int ACT, bool OUT_SPLIT, int FUSE_V>
 __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                           const float *__restrict__ bias, float *__restrict__ C, int M, int Nout,
                                                           int K, const float *__restrict__ W3, float *__restrict__ parts,
                                                           const float *__restrict__ sc) {
     typedef DmaGeom Ge;
-    constexpr int BM = Ge::BM, BN = Ge::BN, ROWW = Ge::ROWW;
+    constexpr int BM = Ge::BM, BN = Ge::BN, ROWW = Ge::ROWW, HALF = Ge::HALF;
     static_assert(OUT_SPLIT != (FUSE_V > 0), "either the split-pair output or the fused last layer");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As0 = smem;                          // [2][BM][ROWW]
-    float *Bs0 = smem + 2 * BM * ROWW;          // [2][BN][ROWW]
+    extern __shared__ __attribute__((aligned(16))) float smem[];     // [k tile parity][A0, B0, B1, A1][128][ROWW]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = (wave >> 2) & 1, wn = wave & 3;
+    const int grp = wave >> 2;                  // waves w and w + 4 share a SIMD: group 1 runs one segment behind group 0
 
     const int nbn = Nout / BN;
     const int nwg = gridDim.x;
@@ -54,80 +66,156 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
     const int tm = wg / nbn, tn = wg - tm * nbn;
     const float out_inv = sc[0], sa_out = sc[1];
 
-    // ---- LDS-DMA staging: this wave fills rows 32 wave .. 32 wave + 31 of the A and of the B tile, 8 rows per instruction.
+    // ---- LDS-DMA staging: this wave fills rows 16 wave .. 16 wave + 15 of every half tile, 8 rows per instruction.
     // Lane = (row in the piece, physical slot); the slot's content is planar slot p = ps ^ (row & 7), i.e. 16-byte chunk
     // 2 (p & 3) + (p >> 2) of the row's 128 bytes in global memory (split-pair order: hi, lo per k group).
-    const int prow = lane >> 3, ps = lane & 7, pp = ps ^ prow;       // (32 wave + 8 q + prow) & 7 == prow
+    const int prow = lane >> 3, ps = lane & 7, pp = ps ^ prow;       // (16 wave + 8 q + prow) & 7 == prow
     const int chunk = 2 * (pp & 3) + (pp >> 2);
-    const float *ag = A + (size_t)(tm * BM + wave * 32 + prow) * K + chunk * 4;
-    const float *wgp = W + (size_t)(tn * BN + wave * 32 + prow) * K + chunk * 4;
-    const size_t piece = (size_t)8 * K;          // floats between two 8-row pieces
-    auto stage = [&](int kt, int buf) {
-        float *ad = As0 + (buf * BM + wave * 32) * ROWW, *bd = Bs0 + (buf * BN + wave * 32) * ROWW;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            __builtin_amdgcn_global_load_lds((gptr_t)(ag + q * piece + (size_t)kt * Ge::BK), (lptr_t)(ad + q * 8 * ROWW), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(wgp + q * piece + (size_t)kt * Ge::BK), (lptr_t)(bd + q * 8 * ROWW), 16, 0, 0);
-        }
+    const float *ag = A + (size_t)(tm * BM + wave * 16 + prow) * K + chunk * 4;
+    const float *wgp = W + (size_t)(tn * BN + wave * 16 + prow) * K + chunk * 4;
+    const size_t piece = (size_t)8 * K, half_rows = (size_t)128 * K;     // floats between two 8-row pieces / the two halves
+    // half tile kinds in slot order: 0 = A rows 0-127, 1 = B rows 0-127, 2 = B rows 128-255, 3 = A rows 128-255
+    auto stage_half = [&](int kt, int kind) {
+        const float *src = ((kind == 0 || kind == 3) ? ag : wgp) + ((kind >= 2) ? half_rows : 0) + (size_t)kt * Ge::BK;
+        float *dst = smem + ((kt & 1) * 4 + kind) * HALF + wave * 16 * ROWW;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + piece), (lptr_t)(dst + 8 * ROWW), 16, 0, 0);
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[2][2][4][2];          // [A half][B half][row tile][column tile]
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment addresses: row l15 of a 16-row tile, k group g; hi slot g ^ (row & 7), lo slot the same ^ 4
+    // fragment addresses inside a half tile: row l15 of a 16-row tile, k group g; hi slot g ^ (row & 7), lo slot that ^ 4
     const int slot_hi = (g ^ (l15 & 7)) * 4;
-    const float *a_hi = As0 + (wm * 128 + l15) * ROWW + slot_hi, *a_lo = As0 + (wm * 128 + l15) * ROWW + (slot_hi ^ 16);
-    const float *b_hi = Bs0 + (wn * 64 + l15) * ROWW + slot_hi, *b_lo = Bs0 + (wn * 64 + l15) * ROWW + (slot_hi ^ 16);
+    const float *fa_hi = smem + (wm * 64 + l15) * ROWW + slot_hi, *fa_lo = smem + (wm * 64 + l15) * ROWW + (slot_hi ^ 16);
+    const float *fb_hi = smem + (wn * 32 + l15) * ROWW + slot_hi, *fb_lo = smem + (wn * 32 + l15) * ROWW + (slot_hi ^ 16);
+    h8 ah[4], al[4], bh[2][2], bl[2][2];
+    auto read_a = [&](int par, int kind) {
+        const int o = (par * 4 + kind) * HALF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ah[i] = *reinterpret_cast<const h8 *>(fa_hi + o + i * 16 * ROWW);
+            al[i] = *reinterpret_cast<const h8 *>(fa_lo + o + i * 16 * ROWW);
+        }
+    };
+    auto read_b = [&](int par, int b) {
+        const int o = (par * 4 + 1 + b) * HALF;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            bh[b][j] = *reinterpret_cast<const h8 *>(fb_hi + o + j * 16 * ROWW);
+            bl[b][j] = *reinterpret_cast<const h8 *>(fb_lo + o + j * 16 * ROWW);
+        }
+    };
+    // 24 MFMAs of one quadrant; the three of one accumulator are seven others apart
+    auto quadrant = [&](int h, int b) {
+        __builtin_amdgcn_s_setprio(1);
+        if constexpr (FUSE_V > 0) {          // D[n][m]: lane <-> batch row
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(bh[b][j], ah[i], acc[h][b][i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(bl[b][j], ah[i], acc[h][b][i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(bh[b][j], al[i], acc[h][b][i][j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(ah[i], bh[b][j], acc[h][b][i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(ah[i], bl[b][j], acc[h][b][i][j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(al[i], bh[b][j], acc[h][b][i][j]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // segment boundary: raw barrier, no fence (a fence would drain the DMA in flight)
+#define DNAG_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+    // end of a load segment: stage half tile (skt, skind) if it exists, retire everything but the four youngest half tiles
+    // (eight pieces of this wave), barrier, wait for the segment's fragment reads
+#ifdef DNAG_GEMM_STAMPS
+    long long st_prev = 0, st_dur[4][4] = {};
+#define DNAG_ST(ph, k) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); \
+        st_dur[ph][k] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DNAG_ST(ph, k)
+#endif
+#define DNAG_LOAD_END(skt, skind, ph)                                                        \
+    do {                                                                                     \
+        if ((skt) < KT) { stage_half(skt, skind); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
+        DNAG_ST(ph, 0);                                                                      \
+        DNAG_BAR();                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
+        DNAG_ST(ph, 1);                                                                      \
+    } while (0)
+#define DNAG_PHASE_END(ph) do { DNAG_ST(ph, 2); DNAG_BAR(); DNAG_ST(ph, 3); } while (0)
 
     const int KT = K / Ge::BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // prologue: all of k tile 0 and the first two half tiles of k tile 1, in the order the phases read them
+    stage_half(0, 0); stage_half(0, 1); stage_half(0, 2); stage_half(0, 3);
+    if (KT > 1) { stage_half(1, 0); stage_half(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DNAG_BAR();
+    if (grp == 1) DNAG_BAR();
+#ifdef DNAG_GEMM_STAMPS
+    st_prev = __builtin_readcyclecounter();
+#endif
+    for (int kt = 0; kt < KT; ++kt) {
+        const int par = kt & 1;
+        // phase 0: quadrant (A0, B0); stages B1 of k tile kt + 1
+        read_b(par, 0);
+        read_a(par, 0);
+        DNAG_LOAD_END(kt + 1, 2, 0);
+        quadrant(0, 0);
+        DNAG_PHASE_END(0);
+        // phase 1: quadrant (A0, B1); stages A1 of k tile kt + 1
+        read_b(par, 1);
+        DNAG_LOAD_END(kt + 1, 3, 1);
+        quadrant(0, 1);
+        DNAG_PHASE_END(1);
+        // phase 2: quadrant (A1, B1); stages A0 of k tile kt + 2 (A0 of kt was last read in phase 0)
+        read_a(par, 3);
+        DNAG_LOAD_END(kt + 2, 0, 2);
+        quadrant(1, 1);
+        DNAG_PHASE_END(2);
+        // phase 3: quadrant (A1, B0), B0 still in registers; stages B0 of k tile kt + 2
+        DNAG_LOAD_END(kt + 2, 1, 3);
+        quadrant(1, 0);
+        DNAG_PHASE_END(3);
+    }
+    if (grp == 0) DNAG_BAR();
+#ifdef DNAG_GEMM_STAMPS
+    if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && (wave & 3) == 0)
+        for (int ph = 0; ph < 4; ++ph)
+            printf("gemm stamps block %d wave %d V %d phase %d: load %lld bar %lld mfma %lld bar %lld (cycles per k tile)\n", (int)blockIdx.x,
+                   wave, FUSE_V, ph, st_dur[ph][0] / KT, st_dur[ph][1] / KT, st_dur[ph][2] / KT, st_dur[ph][3] / KT);
+#endif
+#undef DNAG_PHASE_END
+#undef DNAG_ST
+#undef DNAG_LOAD_END
+#undef DNAG_BAR
     __syncthreads();
 
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) stage(kt + 1, cur ^ 1);      // the other buffer was last read before the barrier that ended tile kt - 1
-        const int ao = cur * BM * ROWW, bo = cur * BN * ROWW;
-        h8 bh[4], bl[4], ah[2], al[2];
-        bh[0] = *reinterpret_cast<const h8 *>(b_hi + bo);
-        bl[0] = *reinterpret_cast<const h8 *>(b_lo + bo);
-        ah[0] = *reinterpret_cast<const h8 *>(a_hi + ao);
-        al[0] = *reinterpret_cast<const h8 *>(a_lo + ao);
-#pragma unroll
-        for (int j = 1; j < 4; ++j) {
-            bh[j] = *reinterpret_cast<const h8 *>(b_hi + bo + j * 16 * ROWW);
-            bl[j] = *reinterpret_cast<const h8 *>(b_lo + bo + j * 16 * ROWW);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = i & 1;
-            if (i + 1 < 8) {        // next row tile's fragments while this one's 12 MFMAs run
-                ah[s ^ 1] = *reinterpret_cast<const h8 *>(a_hi + ao + (i + 1) * 16 * ROWW);
-                al[s ^ 1] = *reinterpret_cast<const h8 *>(a_lo + ao + (i + 1) * 16 * ROWW);
-            }
-            // the three MFMAs of one accumulator are three others apart: no back-to-back dependency
-            if constexpr (FUSE_V > 0) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x(bh[j], ah[s], acc[i][j]);     // D[n][m]: lane <-> batch row
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x(bl[j], ah[s], acc[i][j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x(bh[j], al[s], acc[i][j]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x(ah[s], bh[j], acc[i][j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x(ah[s], bl[j], acc[i][j]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x(al[s], bh[j], acc[i][j]);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt + 1 have landed in LDS
-        __syncthreads();                                      // ... and everybody's; everybody is done reading tile kt
-    }
+    // block-relative row of row tile (h, i) and column of column tile (b, j) of this wave
+    auto row_of = [&](int h, int i) { return h * 128 + wm * 64 + i * 16; };
+    auto col_of = [&](int b, int j) { return b * 128 + wn * 32 + j * 16; };
 
     if constexpr (FUSE_V > 0) {
         constexpr int V = FUSE_V;
@@ -140,80 +228,85 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
         for (int i = tid; i < BN; i += 512) b1s[i] = bias ? bias[tn * BN + i] : 0.f;
         __syncthreads();
         // final.linears.2 on the matrix cores: P[v][row] = sum_col W3[v][col] x[col][row].  A lane holds, for its batch row,
-        // columns 16 j + 4 g + e of column tile j; one 16x16x32 MFMA takes the column tiles (2 pr, 2 pr + 1): k slot 8 g +
-        // 4 t + e of lane group g <-> column 16 (2 pr + t) + 4 g + e, for the W3 fragment (row v = l15) and for x alike.
+        // columns col_of(b, j) + 4 g + e; one 16x16x32 MFMA takes the two column tiles of B half b: k slot 8 g + 4 j + e of
+        // lane group g <-> column col_of(b, j) + 4 g + e, for the W3 fragment (row v = l15) and for x alike.
         h8 w3h[2], w3l[2];
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int j = 0; j < 2; ++j) {
                 v4f w4 = {0.f, 0.f, 0.f, 0.f};
-                if (l15 < V) w4 = *reinterpret_cast<const v4f *>(w3s + l15 * BN + wn * 64 + (2 * pr + t) * 16 + 4 * g);
+                if (l15 < V) w4 = *reinterpret_cast<const v4f *>(w3s + l15 * BN + col_of(b, j) + 4 * g);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     _Float16 hi, lo;
                     split16(w4[e], sw3, hi, lo);
-                    w3h[pr][4 * t + e] = hi; w3l[pr][4 * t + e] = lo;
+                    w3h[b][4 * j + e] = hi; w3l[b][4 * j + e] = lo;
                 }
             }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            f32x4 pa = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                h8 xh, xl;
+            for (int i = 0; i < 4; ++i) {
+                f32x4 pa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int j = 2 * pr + t;
-                    const v4f b4 = *reinterpret_cast<const v4f *>(b1s + wn * 64 + j * 16 + 4 * g);
+                for (int b = 0; b < 2; ++b) {
+                    h8 xh, xl;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = fmaf(acc[i][j][e], out_inv, b4[e]);
-                        if (ACT == ACT_ELU) x = x > 0.f ? x : __expf(x) - 1.0f;
-                        _Float16 hi, lo;
-                        split16(x, sa_out, hi, lo);
-                        xh[4 * t + e] = hi; xl[4 * t + e] = lo;
+                    for (int j = 0; j < 2; ++j) {
+                        const v4f b4 = *reinterpret_cast<const v4f *>(b1s + col_of(b, j) + 4 * g);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float x = fmaf(acc[h][b][i][j][e], out_inv, b4[e]);
+                            if (ACT == ACT_ELU) x = x > 0.f ? x : __expf(x) - 1.0f;
+                            _Float16 hi, lo;
+                            split16(x, sa_out, hi, lo);
+                            xh[4 * j + e] = hi; xl[4 * j + e] = lo;
+                        }
                     }
+                    pa = mfma16x(w3h[b], xh, pa);
+                    pa = mfma16x(w3l[b], xh, pa);
+                    pa = mfma16x(w3h[b], xl, pa);
                 }
-                pa = mfma16x(w3h[pr], xh, pa);
-                pa = mfma16x(w3l[pr], xh, pa);
-                pa = mfma16x(w3h[pr], xl, pa);
-            }
-            // lane (batch row l15 of row tile i, group g) holds P[v = 4 g + e][row]
+                // lane (batch row l15 of row tile (h, i), group g) holds P[v = 4 g + e][row]
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * g + e < V) red[(wn * BM + wm * 128 + i * 16 + l15) * V + 4 * g + e] = pa[e] * out_inv3;
-        }
+                for (int e = 0; e < 4; ++e)
+                    if (4 * g + e < V) red[(wn * BM + row_of(h, i) + l15) * V + 4 * g + e] = pa[e] * out_inv3;
+            }
         __syncthreads();
         float *dst = parts + ((size_t)tn * M + (size_t)tm * BM) * V;
         for (int i = tid; i < BM * V; i += 512)
             dst[i] = (red[i] + red[BM * V + i]) + (red[2 * BM * V + i] + red[3 * BM * V + i]);
         return;
     } else {
-        // epilogue: scale back, bias, activation, split-pair rows.  Lane (column l15 of column tile j, group g) holds rows
-        // 4 g + e of row tile i; lanes 2q, 2q + 1 hold adjacent columns: the even lane stores both hi halves, the odd both lo.
+        // epilogue: scale back, bias, activation, split-pair rows.  Lane (column l15 of a column tile, group g) holds rows
+        // 4 g + e of a row tile; lanes 2q, 2q + 1 hold adjacent columns: the even lane stores both hi halves, the odd both lo.
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = tn * BN + wn * 64 + j * 16 + l15;
-            const float bv = bias ? bias[col] : 0.f;
-            const int c0 = col & ~1;
-            const size_t dw = (split_at(c0) + ((l15 & 1) ? 8 : 0)) >> 1;
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int j = 0; j < 2; ++j) {
+                const int col = tn * BN + col_of(b, j) + l15;
+                const float bv = bias ? bias[col] : 0.f;
+                const int c0 = col & ~1;
+                const size_t dw = (split_at(c0) + ((l15 & 1) ? 8 : 0)) >> 1;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const size_t row = (size_t)(tm * BM + wm * 128 + i * 16 + 4 * g + e);
-                    float v = fmaf(acc[i][j][e], out_inv, bv);
-                    if (ACT == ACT_ELU) v = v > 0.f ? v : __expf(v) - 1.0f;
-                    _Float16 hi, lo;
-                    split16(v, sa_out, hi, lo);
-                    const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, hi), lb = (uint32_t)__builtin_bit_cast(uint16_t, lo);
-                    const uint32_t send = (l15 & 1) ? hb : lb;
-                    const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                    const uint32_t word = (l15 & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
-                    reinterpret_cast<uint32_t *>(C + row * Nout)[dw] = word;
-                }
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const size_t row = (size_t)(tm * BM + row_of(h, i) + 4 * g + e);
+                            float v = fmaf(acc[h][b][i][j][e], out_inv, bv);
+                            if (ACT == ACT_ELU) v = v > 0.f ? v : __expf(v) - 1.0f;
+                            _Float16 hi, lo;
+                            split16(v, sa_out, hi, lo);
+                            const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, hi), lb = (uint32_t)__builtin_bit_cast(uint16_t, lo);
+                            const uint32_t send = (l15 & 1) ? hb : lb;
+                            const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                            const uint32_t word = (l15 & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
+                            reinterpret_cast<uint32_t *>(C + row * Nout)[dw] = word;
+                        }
+                    }
             }
-        }
     }
 }

@@ -1,0 +1,16 @@
+"""One score evaluation at B=4096 with a -DDNAG_GEMM_STAMPS library: prints the kernel's per-phase cycle counts."""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+from diffusionnag_amd import mutils, synthetic, utils
+from diffusionnag_amd import cate  # noqa
+from diffusionnag_amd.specs import CateDims
+from tests.helpers import score_config
+dev = torch.device("cuda:0")
+dims = CateDims()
+model = mutils.create_model(score_config(dims, dev)); model.load_state_dict(synthetic.cate_state_dict(dims, 0)); model.eval()
+X = torch.randn(4096, 8, 7, device=dev); t = torch.full((1,), 500.0, device=dev)
+m = utils.aug_mask(utils.nb201_adj()).to(dev)
+for _ in range(2): model(X, t, m)
+torch.cuda.synchronize()
