@@ -354,4 +354,11 @@ __device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t e, uint32
     const float ang = 6.283185307179586f * u2;
     return (c & 1) ? rad * sinf(ang) : rad * cosf(ang);
 }
+// k-tile-blocked order of split-pair rows: the 128-byte chunk (32 k) number kt of row r moves from [r][kt] to [kt][r], so
+// that the rows of one k tile are contiguous (one 16 KB half tile of dnag_gemm_dma.hip.h = one contiguous run; with
+// row-major rows of 6 KB every line of a k tile fell on the same two memory channels).  K % 32 == 0.
+static inline __host__ __device__ size_t kblock_at(size_t r, size_t dword, size_t rows) { return ((dword >> 5) * rows + r) * 32 + (dword & 31); }
+// the same for an index in units of _Float16 (two per dword)
+static inline __host__ __device__ size_t kblock_half_at(size_t r, size_t half, size_t rows) { return kblock_at(r, half >> 1, rows) * 2 + (half & 1); }
+
 #endif

@@ -271,7 +271,7 @@ __device__ __forceinline__ float drop_apply(float v, uint8_t keep, float keep_pr
 
 // x [batch][N][V]; temb [tstride ? batch : 1][64]; mask [mstride ? batch : 1][N][N];
 // concat [rows_pad][L*64] (row = graph*N + node); attn0 [batch][H][N][N] or null.
-// SPLIT: concat rows are written as split-pair fp16 rows (dnag_gemm16.hip.h) for the fp16-MFMA head GEMM.
+// SPLIT: concat rows are written as k-tile-blocked split-pair fp16 rows (dnag_gemm16.hip.h) for the fp16-MFMA head GEMM.
 // F16: the four linears of every layer run on the split-arithmetic fp16 MFMAs (weights from the frag16 copy at delta16).
 template <int N, int V, int G, int H, int DFF, bool WITH_PE, bool SAVE = false, bool DROP = false, bool SPLIT = false, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict__ P, const CateLayout lay,
@@ -293,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
     const float sa_concat = SPLIT ? P[lay.hsc + HEAD_SC_SA_CONCAT] : 0.f;
+    const size_t rows_pad = ((size_t)batch * N + 255) / 256 * 256;      // SPLIT: the concat is k-tile blocked (dnag_gemm16.hip.h kblock_at)
 #ifdef DNAG_ENC_STAMPS
     long long ts_[96];
     int nts_ = 0;
@@ -582,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                             lo4[e] = (_Float16)(sv16 - (float)hi);
                         }
                         const int k = l * D + 4 * sub;
-                        _Float16 *dst = reinterpret_cast<_Float16 *>(concat + ((size_t)g0 * N + r) * lay.F) + (k >> 3) * 16 + (k & 7);
+                        _Float16 *dst = reinterpret_cast<_Float16 *>(concat) + kblock_half_at((size_t)g0 * N + r, (k >> 3) * 16 + (k & 7), rows_pad);
                         *reinterpret_cast<h4_t *>(dst) = hi4;
                         *reinterpret_cast<h4_t *>(dst + 8) = lo4;
                     } else

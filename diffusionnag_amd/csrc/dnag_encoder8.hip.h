@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
     const float sa_concat = P[lay.hsc + HEAD_SC_SA_CONCAT];
+    const size_t rows_pad = ((size_t)batch * N + 255) / 256 * 256;      // the concat is k-tile blocked (dnag_gemm16.hip.h kblock_at)
     const float *P16 = P + lay.delta16;      // fp16 hi/lo fragment copy of the layer matrices
 
     // this wave's tile of the residual stream (P3 / P6 jobs): rows tmt*32 .., columns tnt*32 ..
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 split4(o4 * sa_concat, hi, lo);
                 if (g0 + rr / N < batch) {
                     const int at = (sub >> 1) * 16 + (sub & 1) * 4;
-                    _Float16 *dst = reinterpret_cast<_Float16 *>(concat + ((size_t)g0 * N + rr) * lay.F) + lprev * (2 * D) + at;
+                    _Float16 *dst = reinterpret_cast<_Float16 *>(concat) + kblock_half_at((size_t)g0 * N + rr, lprev * (2 * D) + at, rows_pad);
                     *reinterpret_cast<h4 *>(dst) = hi;
                     *reinterpret_cast<h4 *>(dst + 8) = lo;
                 }

@@ -17,6 +17,8 @@
 // 32x32x16 step holds k = 8h .. 8h+7).  Producers write this format directly (the encoder's output norm, the
 // first GEMM's epilogue, the host packer for the weights), so the GEMM main loop moves bytes and issues MFMAs.
 #pragma once
+#include <vector>
+#include <cstring>
 #include <type_traits>
 
 #include "dnag_common.h"
@@ -45,14 +47,22 @@ static inline void split_pack(const float *W, size_t rows, size_t K, float *out,
         }
 }
 
+// rows -> k-tile-blocked order (dnag_common.h kblock_at), in place.  K % 32 == 0.
+static inline void kblock_rows(float *m, size_t rows, size_t K) {
+    std::vector<float> t(m, m + rows * K);
+    for (size_t r = 0; r < rows; ++r)
+        for (size_t d = 0; d < K; d += 32) memcpy(m + kblock_at(r, d, rows), t.data() + r * K + d, 32 * sizeof(float));
+}
+
 #ifdef __HIPCC__
-// split-pair activation rows -> fp32 (tests and the concat_out of dnag_cate_forward)
-__global__ void unsplit_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows, int K, const float *__restrict__ sa) {
+// k-tile-blocked split-pair activation rows ([rows_pad] of them) -> fp32 (tests and the concat_out of dnag_cate_forward)
+__global__ void unsplit_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows, size_t rows_pad, int K,
+                               const float *__restrict__ sa) {
     const _Float16 *p = reinterpret_cast<const _Float16 *>(in);
     const size_t n = rows * (size_t)K;
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e / K, k = e - r * K;
-        const size_t at = r * 2 * (size_t)K + split_at(k);
+        const size_t at = kblock_half_at(r, split_at(k), rows_pad);
         out[e] = ((float)p[at] + (float)p[at + 8]) / *sa;
     }
 }

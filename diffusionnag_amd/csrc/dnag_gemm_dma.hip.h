@@ -39,12 +39,13 @@ struct DmaGeom {
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-// C = act(A W^T + bias); A [M][K], W [Nout][K] split-pair rows (pitch K floats); sc: the GEMM's power-of-two scales
-// (dnag_common.h HEAD_SC_F0 / _F1).  OUT_SPLIT: C is written as split-pair rows scaled by sc[1] (final.linears.0).
+// C = act(A W^T + bias); A [M][K] split-pair rows (pitch K floats, or k-tile blocked if A_KBLK), W [Nout][K] split-pair
+// rows, k-tile blocked (dnag_gemm16.hip.h kblock_rows); sc: the GEMM's power-of-two scales (dnag_common.h HEAD_SC_F0 /
+// _F1).  OUT_SPLIT: C is written as k-tile-blocked split-pair rows scaled by sc[1] (final.linears.0).
 // FUSE_V > 0: operands swapped (lane <-> batch row) and final.linears.2 (W3 [FUSE_V][Nout]) applied to the ELU output in
 // registers on the same MFMAs; parts [Nout / 256][M][FUSE_V] receives this block's partial sums (dnag_gemm16.hip.h).
 // M and Nout multiples of 256, K a multiple of 32.
-template <int ACT, bool OUT_SPLIT, int FUSE_V>
+template <int ACT, bool OUT_SPLIT, int FUSE_V, bool A_KBLK>
 __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                           const float *__restrict__ bias, float *__restrict__ C, int M, int Nout,
                                                           int K, const float *__restrict__ W3, float *__restrict__ parts,
@@ -71,15 +72,18 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
     // 2 (p & 3) + (p >> 2) of the row's 128 bytes in global memory (split-pair order: hi, lo per k group).
     const int prow = lane >> 3, ps = lane & 7, pp = ps ^ prow;       // (16 wave + 8 q + prow) & 7 == prow
     const int chunk = 2 * (pp & 3) + (pp >> 2);
-    const float *ag = A + (size_t)(tm * BM + wave * 16 + prow) * K + chunk * 4;
-    const float *wgp = W + (size_t)(tn * BN + wave * 16 + prow) * K + chunk * 4;
-    const size_t piece = (size_t)8 * K, half_rows = (size_t)128 * K;     // floats between two 8-row pieces / the two halves
+    // W is k-tile blocked ([k tile][row][32 dwords], kblock_rows), A too if A_KBLK, else row-major with pitch K
+    const size_t a_row = A_KBLK ? ROWW : K, a_kt = A_KBLK ? (size_t)M * ROWW : Ge::BK, w_kt = (size_t)Nout * ROWW;
+    const float *ag = A + (size_t)(tm * BM + wave * 16 + prow) * a_row + chunk * 4;
+    const float *wgp = W + (size_t)(tn * BN + wave * 16 + prow) * ROWW + chunk * 4;
     // half tile kinds in slot order: 0 = A rows 0-127, 1 = B rows 0-127, 2 = B rows 128-255, 3 = A rows 128-255
     auto stage_half = [&](int kt, int kind) {
-        const float *src = ((kind == 0 || kind == 3) ? ag : wgp) + ((kind >= 2) ? half_rows : 0) + (size_t)kt * Ge::BK;
+        const bool isa = (kind == 0 || kind == 3);
+        const size_t row = isa ? a_row : ROWW;
+        const float *src = (isa ? ag : wgp) + ((kind >= 2) ? 128 * row : 0) + (size_t)kt * (isa ? a_kt : w_kt);
         float *dst = smem + ((kt & 1) * 4 + kind) * HALF + wave * 16 * ROWW;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + piece), (lptr_t)(dst + 8 * ROWW), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + 8 * row), (lptr_t)(dst + 8 * ROWW), 16, 0, 0);
     };
 
     f32x4 acc[2][2][4][2];          // [A half][B half][row tile][column tile]
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
                             const uint32_t send = (l15 & 1) ? hb : lb;
                             const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
                             const uint32_t word = (l15 & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
-                            reinterpret_cast<uint32_t *>(C + row * Nout)[dw] = word;
+                            reinterpret_cast<uint32_t *>(C)[kblock_at(row, dw, (size_t)M)] = word;
                         }
                     }
             }

@@ -223,6 +223,8 @@ static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *
         H[HEAD_SC_F1 + 0] = 1.0f / (sa1 * sw1); H[HEAD_SC_F1 + 1] = sa2; H[HEAD_SC_F1 + 2] = sw3; H[HEAD_SC_F1 + 3] = 1.0f / (sa2 * sw3);
         split_pack(out + y.f0_w, Hd, F, out + y.f0_s, sw0);
         split_pack(out + y.f1_w, Hd, Hd, out + y.f1_s, sw1);
+        kblock_rows(out + y.f0_s, Hd, F);
+        kblock_rows(out + y.f1_s, Hd, Hd);
     }
     if (o != dnag_cate_state_floats(&c)) return fail(DNAG_E_ARG, "internal: consumed %zu of %zu floats", o, dnag_cate_state_floats(&c));
     if (pe) memcpy(out + y.pe, pe, (size_t)y.N * d * sizeof(float));
@@ -560,38 +562,15 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
         }
     }
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev0[slot], st));
-#ifdef DNAG_OLD_GEMM   // debug builds: the 32x32x16 register-staged kernel of round 1 (dnag_gemm16.hip.h), for A/B runs
-    // split-arithmetic fp16 MFMA GEMMs (dnag_gemm16.hip.h): final.linears.0 (K = F) reads the encoder's split-pair
-    // concat and writes split-pair rows; final.linears.1 (K = 2F, the timed one) writes fp32 for the exit kernel
-    typedef SplitGeom Ge;
-    if (M % Ge::BM || Nout % Ge::BN || K % GEMM_BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
-    const int grid = (int)(M / Ge::BM) * (Nout / Ge::BN);
-    auto k7 = gemm_split_kernel<ACT_ELU, false, 1, 7>;      // final.linears.1 + final.linears.2 fused, NAS-Bench-201
-    auto k9 = gemm_split_kernel<ACT_ELU, false, 1, 9>;      // same, OFA
-    auto k0 = gemm_split_kernel<ACT_ELU, true, 0>;
-    static LdsAttr a7, a9, a0;
-    if (int rc = ensure_lds(a7, reinterpret_cast<const void *>(k7), Ge::lds_bytes)) return rc;
-    if (int rc = ensure_lds(a9, reinterpret_cast<const void *>(k9), Ge::lds_bytes)) return rc;
-    if (int rc = ensure_lds(a0, reinterpret_cast<const void *>(k0), Ge::lds_bytes)) return rc;
-    SplitF32Args nofa;
-    memset(&nofa, 0, sizeof(nofa));
-    nofa.sc = sc;
-    if (timed) {
-        if (V != 7 && V != 9) return fail(DNAG_E_ARG, "fused head GEMM is built for 7 or 9 output columns, got %d", V);
-        // C receives the partial sums [Nout / 256][M][V] of final.linears.2
-        hipLaunchKernelGGL(V == 7 ? k7 : k9, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, (float *)nullptr, (int)M, Nout, K, W3, C, nofa);
-    } else {
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr, nofa);
-    }
-#else
     // split-arithmetic fp16 MFMA GEMMs (dnag_gemm_dma.hip.h): final.linears.0 (K = F) reads the encoder's split-pair
-    // concat and writes split-pair rows; final.linears.1 (K = 2F, the timed one) applies final.linears.2 in its epilogue
+    // concat and writes split-pair rows, both k-tile blocked; final.linears.1 (K = 2F, the timed one) reads those and
+    // applies final.linears.2 in its epilogue.  Both weight matrices are k-tile blocked (kblock_rows at pack time).
     typedef DmaGeom Ge;
     if (M % Ge::BM || Nout % Ge::BN || K % Ge::BK) return fail(DNAG_E_ARG, "gemm shape %zu x %d x %d not tile aligned", M, Nout, K);
     const int grid = (int)(M / Ge::BM) * (Nout / Ge::BN);
-    auto k7 = gemm_dma_kernel<ACT_ELU, false, 7>;      // final.linears.1 + final.linears.2 fused, NAS-Bench-201
-    auto k9 = gemm_dma_kernel<ACT_ELU, false, 9>;      // same, OFA
-    auto k0 = gemm_dma_kernel<ACT_ELU, true, 0>;
+    auto k7 = gemm_dma_kernel<ACT_ELU, false, 7, true>;      // final.linears.1 + final.linears.2 fused, NAS-Bench-201
+    auto k9 = gemm_dma_kernel<ACT_ELU, false, 9, true>;      // same, OFA
+    auto k0 = gemm_dma_kernel<ACT_ELU, true, 0, true>;
     static LdsAttr a7, a9, a0;
     if (int rc = ensure_lds(a7, reinterpret_cast<const void *>(k7), Ge::lds_bytes)) return rc;
     if (int rc = ensure_lds(a9, reinterpret_cast<const void *>(k9), Ge::lds_bytes)) return rc;
@@ -603,7 +582,6 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
     } else {
         hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr, sc);
     }
-#endif
     LAUNCH_CHECK();
     if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
     return 0;
@@ -730,7 +708,7 @@ extern "C" int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, c
     a.parts = ws + w.h2; a.nparts = lay.Hd / SplitGeom::BN; a.part_stride = w.rows_pad * (size_t)lay.V;
     if (int rc = launch_exit(*d, lay, packed, ws + w.h2, a, st)) return rc;
     if (concat_out) {   // the workspace holds split-pair rows; hand back plain fp32
-        hipLaunchKernelGGL(unsplit_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, lay.F, packed + lay.hsc + HEAD_SC_SA_CONCAT);
+        hipLaunchKernelGGL(unsplit_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, w.rows_pad, lay.F, packed + lay.hsc + HEAD_SC_SA_CONCAT);
         LAUNCH_CHECK();
     }
     return 0;

@@ -123,7 +123,9 @@ def test_cate_pack_folds_layernorm_into_linear():
     for l in range(12):
         sc = raw_all[layer0 + l * stride + stride - 8 - 576: layer0 + (l + 1) * stride - 576]
         assert list(sc[:6]) == [1.0 / 4096, 16.0, 1.0 / 4096, 1.0 / 4096, 16.0, 1.0 / 4096], (l, sc)
-    halves = raw[: 1536 * 768].view(np.float16).reshape(1536, 768 // 8, 2, 8).astype(np.float64)
+    # ... stored k-tile blocked (kblock_rows): [k tile of 32][row][32 dwords]
+    rows_major = raw[: 1536 * 768].reshape(768 // 32, 1536, 32).transpose(1, 0, 2).reshape(-1).copy()
+    halves = rows_major.view(np.float16).reshape(1536, 768 // 8, 2, 8).astype(np.float64)
     w0 = sd["final.linears.0.weight"].double().numpy()
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 768) / 256.0
     assert np.abs(rec - w0).max() <= 2.0 ** -21 * np.abs(w0).max()
@@ -174,6 +176,7 @@ def test_cate_pack_scales_follow_large_weights():
     assert sa2 * h2b <= 60000 * 1.001 and (sa2 == 16 or 2 * sa2 * h2b > 60000)
     # the split-pair copy of final.linears.1 carries sw1 and reproduces the weights to 22 bits, 300 included
     f1s = raw[-n_split - 16 - n_l16 + 1536 * 768: -16 - n_l16]
+    f1s = f1s.reshape(1536 // 32, 1536, 32).transpose(1, 0, 2).reshape(-1).copy()       # k-tile blocked -> rows
     halves = f1s.view(np.float16).reshape(1536, 1536 // 8, 2, 8).astype(np.float64)
     assert np.isfinite(halves).all()
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 1536) / sw1
