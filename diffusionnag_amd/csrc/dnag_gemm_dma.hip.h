@@ -29,6 +29,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16x(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
+#ifndef X_WAIT
+#define X_WAIT "s_waitcnt vmcnt(8)"
+#endif
 struct DmaGeom {
     static constexpr int BM = 256, BN = 256, BK = 32, T = 512;
     static constexpr int ROWW = 32;                                   // dwords per staged row (32 k: 16 of hi, 16 of lo)
@@ -119,7 +122,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
     };
     // 24 MFMAs of one quadrant; the three of one accumulator are seven others apart
     auto quadrant = [&](int h, int b) {
+#ifndef X_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         if constexpr (FUSE_V > 0) {          // D[n][m]: lane <-> batch row
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -147,14 +152,16 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(al[i], bh[b][j], acc[h][b][i][j]);
         }
+#ifndef X_NOPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
     // segment boundary: raw barrier, no fence (a fence would drain the DMA in flight)
 #define DNAG_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
     // end of a load segment: stage half tile (skt, skind) if it exists, retire everything but the four youngest half tiles
     // (eight pieces of this wave), barrier, wait for the segment's fragment reads
 #ifdef DNAG_GEMM_STAMPS
-    long long st_prev = 0, st_dur[4][4] = {};
+    long long st_prev = 0, st_dur[4][6] = {};
 #define DNAG_ST(ph, k) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); \
         st_dur[ph][k] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -162,7 +169,8 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
 #endif
 #define DNAG_LOAD_END(skt, skind, ph)                                                        \
     do {                                                                                     \
-        if ((skt) < KT) { stage_half(skt, skind); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); } \
+        DNAG_ST(ph, 4);                                                                      \
+        if ((skt) < KT) { stage_half(skt, skind); DNAG_ST(ph, 5); asm volatile(X_WAIT ::: "memory"); } \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
         DNAG_ST(ph, 0);                                                                      \
         DNAG_BAR();                                                                          \
@@ -172,19 +180,22 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
 #define DNAG_PHASE_END(ph) do { DNAG_ST(ph, 2); DNAG_BAR(); DNAG_ST(ph, 3); } while (0)
 
     const int KT = K / Ge::BK;
-    // prologue: all of k tile 0 and the first two half tiles of k tile 1, in the order the phases read them
-    stage_half(0, 0); stage_half(0, 1); stage_half(0, 2); stage_half(0, 3);
-    if (KT > 1) { stage_half(1, 0); stage_half(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    // prologue: all of k tile 0 and the first two half tiles of k tile 1, in the order the phases read them; B0 of k tile 0
+    // is read here, B0 of every later k tile in phase 3 of the k tile before (fragment reads per phase: 8, 4, 8, 4)
+    stage_half(0, 1); stage_half(0, 0); stage_half(0, 2); stage_half(0, 3);
+    if (KT > 1) { stage_half(1, 1); stage_half(1, 0); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DNAG_BAR();
+    read_b(0, 0);
+#ifndef X_NOSTAG
     if (grp == 1) DNAG_BAR();
+#endif
 #ifdef DNAG_GEMM_STAMPS
     st_prev = __builtin_readcyclecounter();
 #endif
     for (int kt = 0; kt < KT; ++kt) {
         const int par = kt & 1;
         // phase 0: quadrant (A0, B0); stages B1 of k tile kt + 1
-        read_b(par, 0);
         read_a(par, 0);
         DNAG_LOAD_END(kt + 1, 2, 0);
         quadrant(0, 0);
@@ -194,22 +205,25 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
         DNAG_LOAD_END(kt + 1, 3, 1);
         quadrant(0, 1);
         DNAG_PHASE_END(1);
-        // phase 2: quadrant (A1, B1); stages A0 of k tile kt + 2 (A0 of kt was last read in phase 0)
+        // phase 2: quadrant (A1, B0); stages B0 of k tile kt + 2 (B0 of kt was last read in phase 3 of kt - 1)
         read_a(par, 3);
-        DNAG_LOAD_END(kt + 2, 0, 2);
-        quadrant(1, 1);
-        DNAG_PHASE_END(2);
-        // phase 3: quadrant (A1, B0), B0 still in registers; stages B0 of k tile kt + 2
-        DNAG_LOAD_END(kt + 2, 1, 3);
+        DNAG_LOAD_END(kt + 2, 1, 2);
         quadrant(1, 0);
+        DNAG_PHASE_END(2);
+        // phase 3: quadrant (A1, B1); reads B0 of k tile kt + 1 (retired in phase 2), stages A0 of k tile kt + 2
+        if (kt + 1 < KT) read_b(par ^ 1, 0);
+        DNAG_LOAD_END(kt + 2, 0, 3);
+        quadrant(1, 1);
         DNAG_PHASE_END(3);
     }
+#ifndef X_NOSTAG
     if (grp == 0) DNAG_BAR();
+#endif
 #ifdef DNAG_GEMM_STAMPS
     if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && (wave & 3) == 0)
         for (int ph = 0; ph < 4; ++ph)
-            printf("gemm stamps block %d wave %d V %d phase %d: load %lld bar %lld mfma %lld bar %lld (cycles per k tile)\n", (int)blockIdx.x,
-                   wave, FUSE_V, ph, st_dur[ph][0] / KT, st_dur[ph][1] / KT, st_dur[ph][2] / KT, st_dur[ph][3] / KT);
+            printf("gemm stamps block %d wave %d V %d phase %d: reads %lld dma %lld vmcnt %lld bar %lld mfma %lld bar %lld (cycles per k tile)\n", (int)blockIdx.x,
+                   wave, FUSE_V, ph, st_dur[ph][4] / KT, st_dur[ph][5] / KT, st_dur[ph][0] / KT, st_dur[ph][1] / KT, st_dur[ph][2] / KT, st_dur[ph][3] / KT);
 #endif
 #undef DNAG_PHASE_END
 #undef DNAG_ST
