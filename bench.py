@@ -32,18 +32,19 @@ from diffusionnag_amd.specs import CateDims, PredictorCateDims, PredictorDims  #
 # algorithmic FLOPs (2 per MAC) of one guided sample (2000 score evaluations + guidance gradients): SURVEY.md section 8d
 FLOP_PER_SAMPLE = {"nb201": 136.3e9, "ofa": 345.4e9}
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: BF16/F16 ~2.5 PF dense (a bare v_mfma_f32_32x32x16_f16 loop sustains ~1950 on this
-                                  # chip, tests/micro/gemm16_bench.hip)
-# The dominant kernel computes in split arithmetic (diffusionnag_amd/csrc/dnag_gemm16.hip.h): every fp32-accurate
+PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: BF16/F16 ~2.5 PF dense (a bare v_mfma_f32_16x16x32_f16 loop sustains ~1840 on this
+                                  # chip on random operands, tests/micro/mfma_shapes.hip)
+# The dominant kernel computes in split arithmetic (diffusionnag_amd/csrc/dnag_gemm_dma.hip.h): every fp32-accurate
 # product costs THREE fp16 MFMAs, so `achieved` (ALGORITHMIC flops / time, as the contract defines it) can reach at
 # most a third of the fp16 peak; `mfma_issued_*` gives the matrix-core utilisation proper.
 SPLIT_MFMA_PER_PRODUCT = 3
 # Fabric-side bytes of ONE launch of the dominant kernel (final.linears.1 at B=4096, NB201) from PMC counters:
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as the guide's HBM
-# section prescribes for gfx950 (profiles/r01i_pmc_traffic.json: 0.456 GB read + 0.006 GB written; algorithmic
-# bytes 0.218 GB = A 201 MB + W 9.4 MB + the fused final.linears.2 partial sums 7.3 MB).  Counters cannot be collected inside this process, so the figure is quoted only for the shape it
+# section prescribes for gfx950 (profiles/r02c_pmc_traffic.json: 0.454 GB read + 0.006 GB written; algorithmic
+# bytes 0.218 GB = A 201 MB + W 9.4 MB + the fused final.linears.2 partial sums 7.3 MB; the excess is the weight
+# matrix fetched once per XCD and round of tiles, 8 x 3 x 9.4 MB, out of the Infinity Cache).  Counters cannot be collected inside this process, so the figure is quoted only for the shape it
 # was measured on.
-PMC_TRAFFIC_BYTES = {("nb201", 4096): 461476864}
+PMC_TRAFFIC_BYTES = {("nb201", 4096): 459913216}
 
 
 class Cfg(dict):
@@ -282,15 +283,15 @@ def bench_sampling(a, workload, steps, warmup):
                                     "Philox noise on device"),
                        "batch_per_gpu": B, "global_batch": total, "pc_steps": a.sde_steps,
                        "score_evals_per_sample": 2 * a.sde_steps, "parallelism": f"batch-shard x{world}"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_split_kernel<ELU,false,1,V> (final.linears.1, M x 1536 x 1536, with final.linears.2 fused into its epilogue; fp32-accurate "
-                                                    "hi/lo split on v_mfma_f32_32x32x16_f16, 3 MFMAs per product)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<ELU,false,V,true> (final.linears.1, M x 1536 x 1536, with final.linears.2 fused into its epilogue; fp32-accurate "
+                                                    "hi/lo split on v_mfma_f32_16x16x32_f16, 3 MFMAs per product)",
                          "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F16_MFMA_TFLOPS,
                          "mfma_issued_tflops": achieved * SPLIT_MFMA_PER_PRODUCT,
                          "mfma_issued_frac": achieved * SPLIT_MFMA_PER_PRODUCT / PEAK_F16_MFMA_TFLOPS,
                          "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((workload, B)),
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01i_pmc_traffic.json)",
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02c_pmc_traffic.json)",
                          "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value},
             "whole_path_tflops": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world,
             "whole_path_frac_of_f32_mfma_peak": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,

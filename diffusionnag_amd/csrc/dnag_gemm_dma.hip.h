@@ -300,21 +300,26 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
         // epilogue: scale back, bias, activation, split-pair rows.  Lane (column l15 of a column tile, group g) holds rows
         // 4 g + e of a row tile; lanes 2q, 2q + 1 hold adjacent columns: the even lane stores both hi halves, the odd both lo.
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            float bv[2];
+            size_t dw[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int col = tn * BN + col_of(b, j) + l15;
-                const float bv = bias ? bias[col] : 0.f;
-                const int c0 = col & ~1;
-                const size_t dw = (split_at(c0) + ((l15 & 1) ? 8 : 0)) >> 1;
+                bv[j] = bias ? bias[col] : 0.f;
+                dw[j] = (split_at(col & ~1) + ((l15 & 1) ? 8 : 0)) >> 1;
+            }
+            // the two column tiles of a B half share every 128-byte line of the output (64 bytes each): stored back to back
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const size_t row = (size_t)(tm * BM + row_of(h, i) + 4 * g + e);
-                            float v = fmaf(acc[h][b][i][j][e], out_inv, bv);
+                    for (int e = 0; e < 4; ++e) {
+                        const size_t row = (size_t)(tm * BM + row_of(h, i) + 4 * g + e);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            float v = fmaf(acc[h][b][i][j][e], out_inv, bv[j]);
                             if (ACT == ACT_ELU) v = v > 0.f ? v : __expf(v) - 1.0f;
                             _Float16 hi, lo;
                             split16(v, sa_out, hi, lo);
@@ -322,9 +327,9 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
                             const uint32_t send = (l15 & 1) ? hb : lb;
                             const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
                             const uint32_t word = (l15 & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
-                            reinterpret_cast<uint32_t *>(C)[kblock_at(row, dw, (size_t)M)] = word;
+                            reinterpret_cast<uint32_t *>(C)[kblock_at(row, dw[j], (size_t)M)] = word;
                         }
                     }
-            }
+        }
     }
 }
