@@ -161,9 +161,10 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
     // end of a load segment: stage half tile (skt, skind) if it exists, retire everything but the four youngest half tiles
     // (eight pieces of this wave), barrier, wait for the segment's fragment reads
 #ifdef DNAG_GEMM_STAMPS
-    long long st_prev = 0, st_dur[4][6] = {};
-#define DNAG_ST(ph, k) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); \
-        st_dur[ph][k] += now_ - st_prev; st_prev = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
+    // stamps are only RECORDED inside a k tile (s_memtime into separate SGPRs, no use, so no lgkmcnt wait that would also
+    // drain the LDS reads) and turned into durations once per k tile, after its last barrier
+    long long st_prev = 0, st_raw[4][6], st_dur[4][6] = {};
+#define DNAG_ST(ph, k) do { st_raw[ph][k] = __builtin_readcyclecounter(); } while (0)
 #else
 #define DNAG_ST(ph, k)
 #endif
@@ -215,6 +216,20 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
         DNAG_LOAD_END(kt + 2, 0, 3);
         quadrant(1, 1);
         DNAG_PHASE_END(3);
+#ifdef DNAG_GEMM_STAMPS
+        {
+            constexpr int order[6] = {4, 5, 0, 1, 2, 3};
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
+                    const int k = order[q];
+                    if (k == 5 && !((ph < 2 ? kt + 1 : kt + 2) < KT)) { continue; }
+                    st_dur[ph][k] += st_raw[ph][k] - st_prev;
+                    st_prev = st_raw[ph][k];
+                }
+        }
+#endif
     }
 #ifndef X_NOSTAG
     if (grp == 0) DNAG_BAR();

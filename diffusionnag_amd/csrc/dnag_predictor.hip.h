@@ -260,31 +260,42 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     // the split).  The power-of-two scale must be known before the first value is written, so it comes from a bound:
     // the producer of Hb noted max |Hb| in amaxv[ph]; A1 and A2 are row-normalised with non-negative entries, so
     // |A H| <= max |H| (forward), and |A^T D| <= max |D| * (largest column sum of A1 / A2, colsum_max) (backward).
-    auto put_split = [&](float *U, int row, int at, float v, float sa) {
-        _Float16 hi, lo;
-        split16(v, sa, hi, lo);
+    // two adjacent columns (c even) of one row: the hi halves are one dword, the lo halves the dword 8 halves on
+    auto put_split2 = [&](float *U, int row, int at, float v0, float v1, float sa) {
+        _Float16 h0, l0, h1, l1;
+        split16(v0, sa, h0, l0);
+        split16(v1, sa, h1, l1);
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         _Float16 *d = reinterpret_cast<_Float16 *>(U + row * HS) + at;
-        d[0] = hi;
-        d[8] = lo;
+        *reinterpret_cast<h2 *>(d) = h2{h0, h1};
+        *reinterpret_cast<h2 *>(d + 8) = h2{l0, l1};
     };
-    auto mix_fwd = [&](int ph) {   // U1 = A1 H, U2 = A2 H
+    static_assert(GH % 2 == 0 && HS % 2 == 0, "mixing items are column pairs");
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    auto mix_fwd = [&](int ph) {   // U1 = A1 H, U2 = A2 H; one (graph, column pair) per thread
         const float sa = pow2_scale(__uint_as_float(amaxv[ph]));
-        for (int i = tid; i < G * GH; i += NT) {
-            const int g = i / GH, c = i - g * GH;
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));       // the item's LDS addresses are computed here, not hoisted out of the layer loop (spills)
+#pragma unroll 1
+        for (int i = t0; i < G * (GH / 2); i += NT) {
+            const int g = i / (GH / 2), c = 2 * (i - g * (GH / 2));
             const int at = (c >> 3) * 16 + (c & 7);          // split_at(c), in halves
-            float hv[N];
+            f2v hv[N];
 #pragma unroll
-            for (int j = 0; j < N; ++j) hv[j] = Hb[(g * N + j) * HS + c];
+            for (int j = 0; j < N; ++j) hv[j] = *reinterpret_cast<const f2v *>(Hb + (g * N + j) * HS + c);
 #pragma unroll
             for (int n = 0; n < N; ++n) {
                 float a1[N], a2[N];
                 load_row<N>(A1 + (g * N + n) * N, a1);
                 load_row<N>(A2 + (g * N + n) * N, a2);
-                float u1 = 0.f, u2 = 0.f;
+                float u1x = 0.f, u1y = 0.f, u2x = 0.f, u2y = 0.f;
 #pragma unroll
-                for (int j = 0; j < N; ++j) { u1 = fmaf(a1[j], hv[j], u1); u2 = fmaf(a2[j], hv[j], u2); }
-                put_split(U1, g * N + n, at, u1, sa);
-                put_split(U2, g * N + n, at, u2, sa);
+                for (int j = 0; j < N; ++j) {
+                    u1x = fmaf(a1[j], hv[j].x, u1x); u1y = fmaf(a1[j], hv[j].y, u1y);
+                    u2x = fmaf(a2[j], hv[j].x, u2x); u2y = fmaf(a2[j], hv[j].y, u2y);
+                }
+                put_split2(U1, g * N + n, at, u1x, u1y, sa);
+                put_split2(U2, g * N + n, at, u2x, u2y, sa);
             }
         }
         return sa;
@@ -293,31 +304,39 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     auto mix_bwd = [&](int l, int ph) {
         const uint32_t *bl = bits + (size_t)l * BL;
         const float sa = pow2_scale(__uint_as_float(amaxv[ph]) * 0.5f * __uint_as_float(colsum_max));
-        for (int i = tid; i < G * GH; i += NT) {
-            const int g = i / GH, c = i - g * GH;
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));       // the item's LDS addresses are computed here, not hoisted out of the layer loop (spills)
+#pragma unroll 1
+        for (int i = t0; i < G * (GH / 2); i += NT) {
+            const int g = i / (GH / 2), c = 2 * (i - g * (GH / 2));
             const int at = (c >> 3) * 16 + (c & 7);
             // rows 8g .. 8g+7 = row tile g >> 2, rows-in-tile 8 (g & 3) + j: half j >> 2, register (j & 3) + 4 (g & 3)
-            const uint32_t bw[2] = {bl[((g >> 2) * 2 + 0) * BW + c], bl[((g >> 2) * 2 + 1) * BW + c]};
-            float p1[N], p2[N];
+            const uint32_t bw0[2] = {bl[((g >> 2) * 2 + 0) * BW + c], bl[((g >> 2) * 2 + 1) * BW + c]};
+            const uint32_t bw1[2] = {bl[((g >> 2) * 2 + 0) * BW + c + 1], bl[((g >> 2) * 2 + 1) * BW + c + 1]};
+            float p1x[N], p1y[N], p2x[N], p2y[N];
 #pragma unroll
-            for (int n = 0; n < N; ++n) { p1[n] = 0.f; p2[n] = 0.f; }
+            for (int n = 0; n < N; ++n) { p1x[n] = 0.f; p1y[n] = 0.f; p2x[n] = 0.f; p2y[n] = 0.f; }
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const int rj = g * N + j;
-                const float dh = Hb[rj * HS + c] * 0.5f;
+                const f2v dh2 = *reinterpret_cast<const f2v *>(Hb + rj * HS + c);
+                const float dhx = dh2.x * 0.5f, dhy = dh2.y * 0.5f;
                 const int bi = (j & 3) + 4 * (g & 3);
-                const float d1 = ((bw[j >> 2] >> bi) & 1u) ? dh : 0.f;
-                const float d2 = ((bw[j >> 2] >> (16 + bi)) & 1u) ? dh : 0.f;
+                const float d1x = ((bw0[j >> 2] >> bi) & 1u) ? dhx : 0.f, d2x = ((bw0[j >> 2] >> (16 + bi)) & 1u) ? dhx : 0.f;
+                const float d1y = ((bw1[j >> 2] >> bi) & 1u) ? dhy : 0.f, d2y = ((bw1[j >> 2] >> (16 + bi)) & 1u) ? dhy : 0.f;
                 float a1[N], a2[N];
                 load_row<N>(A1 + rj * N, a1);
                 load_row<N>(A2 + rj * N, a2);
 #pragma unroll
-                for (int n = 0; n < N; ++n) { p1[n] = fmaf(a1[n], d1, p1[n]); p2[n] = fmaf(a2[n], d2, p2[n]); }
+                for (int n = 0; n < N; ++n) {
+                    p1x[n] = fmaf(a1[n], d1x, p1x[n]); p1y[n] = fmaf(a1[n], d1y, p1y[n]);
+                    p2x[n] = fmaf(a2[n], d2x, p2x[n]); p2y[n] = fmaf(a2[n], d2y, p2y[n]);
+                }
             }
 #pragma unroll
             for (int n = 0; n < N; ++n) {
-                put_split(U1, g * N + n, at, p1[n], sa);
-                put_split(U2, g * N + n, at, p2[n], sa);
+                put_split2(U1, g * N + n, at, p1x[n], p1y[n], sa);
+                put_split2(U2, g * N + n, at, p2x[n], p2y[n], sa);
             }
         }
         return sa;
