@@ -181,12 +181,18 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
 #define DNAG_PHASE_END(ph) do { DNAG_ST(ph, 2); DNAG_BAR(); DNAG_ST(ph, 3); } while (0)
 
     const int KT = K / Ge::BK;
+#ifdef DNAG_GEMM_TILE_STAMPS
+    const long long tw0 = wall_clock64();
+#endif
     // prologue: all of k tile 0 and the first two half tiles of k tile 1, in the order the phases read them; B0 of k tile 0
     // is read here, B0 of every later k tile in phase 3 of the k tile before (fragment reads per phase: 8, 4, 8, 4)
     stage_half(0, 1); stage_half(0, 0); stage_half(0, 2); stage_half(0, 3);
     if (KT > 1) { stage_half(1, 1); stage_half(1, 0); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     DNAG_BAR();
+#ifdef DNAG_GEMM_TILE_STAMPS
+    const long long tw1 = wall_clock64();
+#endif
     read_b(0, 0);
 #ifndef X_NOSTAG
     if (grp == 1) DNAG_BAR();
@@ -245,6 +251,13 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
 #undef DNAG_LOAD_END
 #undef DNAG_BAR
     __syncthreads();
+#ifdef DNAG_GEMM_TILE_STAMPS
+    const long long tw2 = wall_clock64();
+#define DNAG_TILE_REPORT() do { if (tid == 0) { unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); \
+        printf("tile V %d blk %d xcc %u cu %u se %u : start %lld prologue %lld loop %lld epilogue %lld\n", FUSE_V, (int)blockIdx.x, xcc & 15, (hwid >> 8) & 15, (hwid >> 13) & 7, tw0, tw1 - tw0, tw2 - tw1, wall_clock64() - tw2); } } while (0)
+#else
+#define DNAG_TILE_REPORT()
+#endif
 
     // block-relative row of row tile (h, i) and column of column tile (b, j) of this wave
     auto row_of = [&](int h, int i) { return h * 128 + wm * 64 + i * 16; };
@@ -310,41 +323,59 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
         float *dst = parts + ((size_t)tn * M + (size_t)tm * BM) * V;
         for (int i = tid; i < BM * V; i += 512)
             dst[i] = (red[i] + red[BM * V + i]) + (red[2 * BM * V + i] + red[3 * BM * V + i]);
+        DNAG_TILE_REPORT();
         return;
     } else {
-        // epilogue: scale back, bias, activation, split-pair rows.  Lane (column l15 of a column tile, group g) holds rows
-        // 4 g + e of a row tile; lanes 2q, 2q + 1 hold adjacent columns: the even lane stores both hi halves, the odd both lo.
+        // epilogue: scale back, bias, activation, k-tile-blocked split-pair rows, staged through LDS.  In the blocked layout
+        // the 32 columns x 256 rows of one output k tile are 32 KB of contiguous memory, and a wave's 32 columns of a B
+        // half are exactly one k tile: per B half the block writes its 128 KB image [k tile wn][row][128 B] into LDS (two
+        // 2-byte writes per value; 16-byte slot s of row r at slot s ^ ((r >> 2) & 7), which spreads the four row groups of
+        // a write over the banks) and copies it out with 16-byte loads and fully coalesced 1 KB stores (dword stores from
+        // the accumulator layout kept the address path busy for 15 us per tile).
+        // Lane (column l15 of a column tile, group g) holds rows 4 g + e of a row tile.
+        _Float16 *img = reinterpret_cast<_Float16 *>(smem);
+        const float *imgf = smem;
+        const int ktg0 = (tn * BN) / 32;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            float bv[2];
-            size_t dw[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int col = tn * BN + col_of(b, j) + l15;
-                bv[j] = bias ? bias[col] : 0.f;
-                dw[j] = (split_at(col & ~1) + ((l15 & 1) ? 8 : 0)) >> 1;
-            }
-            // the two column tiles of a B half share every 128-byte line of the output (64 bytes each): stored back to back
+                const int k = j * 16 + l15;                                  // column inside the wave's k tile
+                const float bv = bias ? bias[tn * BN + col_of(b, j) + l15] : 0.f;
+                const int slot = (k >> 3) * 2, within = k & 7;               // hi slot; the lo slot is the next one
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const size_t row = (size_t)(tm * BM + row_of(h, i) + 4 * g + e);
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            float v = fmaf(acc[h][b][i][j][e], out_inv, bv[j]);
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = row_of(h, i) + 4 * g + e;
+                            float v = fmaf(acc[h][b][i][j][e], out_inv, bv);
                             if (ACT == ACT_ELU) v = v > 0.f ? v : __expf(v) - 1.0f;
                             _Float16 hi, lo;
                             split16(v, sa_out, hi, lo);
-                            const uint32_t hb = (uint32_t)__builtin_bit_cast(uint16_t, hi), lb = (uint32_t)__builtin_bit_cast(uint16_t, lo);
-                            const uint32_t send = (l15 & 1) ? hb : lb;
-                            const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-                            const uint32_t word = (l15 & 1) ? (recv | (lb << 16)) : (hb | (recv << 16));
-                            reinterpret_cast<uint32_t *>(C)[kblock_at(row, dw[j], (size_t)M)] = word;
+                            const int sw = (row >> 2) & 7;
+                            _Float16 *rp = img + (size_t)(wn * BM + row) * 64;
+                            rp[((slot ^ sw) << 3) + within] = hi;
+                            rp[(((slot + 1) ^ sw) << 3) + within] = lo;
                         }
-                    }
+            }
+            __syncthreads();
+#ifdef DNAG_GEMM_TILE_STAMPS
+            if (b == 0 && tid == 0 && blockIdx.x < 4) printf("  epi blk %d: values+lds of half 0 done at %lld\n", (int)blockIdx.x, wall_clock64() - tw2);
+#endif
+            // copy out: chunk c = 8 rows x 128 B of k tile c / 32; lane = (row of the chunk, 16-byte slot)
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int c = q * 8 + wave, kt2 = c >> 5, row = (c & 31) * 8 + (lane >> 3), sl = lane & 7;
+                const v4f val = *reinterpret_cast<const v4f *>(imgf + (size_t)(kt2 * BM + row) * 32 + ((sl ^ ((row >> 2) & 7)) << 2));
+                *reinterpret_cast<v4f *>(C + ((size_t)(ktg0 + b * 4 + kt2) * M + (size_t)tm * BM + row) * 32 + sl * 4) = val;
+            }
+            __syncthreads();
+#ifdef DNAG_GEMM_TILE_STAMPS
+            if (b == 0 && tid == 0 && blockIdx.x < 4) printf("  epi blk %d: copy of half 0 done at %lld\n", (int)blockIdx.x, wall_clock64() - tw2);
+#endif
         }
+        DNAG_TILE_REPORT();
     }
 }
