@@ -24,6 +24,7 @@
 
 #define PRED_GH 144        // gcn_hidden (configs/tr_meta_surrogate.py:97)
 #define PRED_HS 148        // LDS row stride of [R][144] buffers (148 % 64 == 20: conflict-free b128 reads)
+#define PRED_HT 68         // row stride of the transposed activation buffer [144 columns][64 rows] (68 % 64 == 4: conflict-free b128)
 #define PRED_NT 5          // ceil(144 / 32) column tiles
 #define PRED_G 8           // graphs per workgroup
 #define PRED_NW 10         // waves per workgroup: one (column tile, row tile) job each
@@ -39,8 +40,9 @@ struct PredGeom {
     // dynamic LDS bytes for `hs` head units and `L` DiGCN layers
     static size_t lds_bytes(int hs, int L) {
         const size_t hs4 = align4((size_t)hs);
-        const size_t fl = 3 * (size_t)R * PRED_HS      // H, U1, U2
-                          + 2 * (size_t)G * N * N      // A1, A2
+        const size_t fl = (size_t)PRED_GH * PRED_HT    // H^T
+                          + 2 * (size_t)R * PRED_HS    // U1, U2
+                          + 4 * (size_t)G * N * N      // A1, A2 and their transposes
                           + (size_t)(G + 1) * hs4      // tanh / dpre, c0
                           + 3 * (size_t)R * XS         // x, A1 x, A2 x
                           + (size_t)L * 2 * R * PRED_NT;   // relu bit masks (uint32)
@@ -97,14 +99,18 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     static_assert(N == 8, "adjacency mixing is written for 8-node graphs");
     constexpr int G = Ge::G, R = Ge::R, MT = Ge::MT, HS = PRED_HS, GH = PRED_GH, NT = PRED_NW * 64, LH = 128, XS = Ge::XS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Hb = smem;                       // [R][HS]
-    float *U1 = Hb + R * HS;                // [R][HS]
+    constexpr int HT = PRED_HT;
+    static_assert(R == 64 && HT >= R + 4, "H^T rows hold the workgroup's 64 rows");
+    float *HbT = smem;                      // [GH][HT]: activations / their gradients, TRANSPOSED (column-major over the rows)
+    float *U1 = HbT + GH * HT;              // [R][HS]
     float *U2 = U1 + R * HS;                // [R][HS]
     float *A1 = U2 + R * HS;                // [G][N][N]
     float *A2 = A1 + G * N * N;             // [G][N][N]
+    float *A1T = A2 + G * N * N;            // [G][N][N] transposes (backward mixing)
+    float *A2T = A1T + G * N * N;
     const int L = lay.L, hs = lay.hs, nz = lay.nz;
     const int TS = (hs + 3) & ~3;           // row stride of tv
-    float *tv = A2 + G * N * N;             // [G][TS]
+    float *tv = A2T + G * N * N;            // [G][TS]
     float *c0 = tv + G * TS;                // [TS]
     float *xin = c0 + TS;                   // [R][XS]
     float *ux1 = xin + R * XS;              // [R][XS] A1 x
@@ -172,8 +178,11 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         for (int j = 0; j < N; ++j) { s1 += Ah[(g * N + r) * N + j]; s2 += Ah[(g * N + j) * N + r]; }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            A1[(g * N + r) * N + j] = Ah[(g * N + r) * N + j] / s1;
-            A2[(g * N + r) * N + j] = Ah[(g * N + j) * N + r] / s2;
+            const float a1v = Ah[(g * N + r) * N + j] / s1, a2v = Ah[(g * N + j) * N + r] / s2;
+            A1[(g * N + r) * N + j] = a1v;
+            A2[(g * N + r) * N + j] = a2v;
+            A1T[(g * N + j) * N + r] = a1v;
+            A2T[(g * N + j) * N + r] = a2v;
         }
     }
     // c0 = b0 + W0[:, :nz] D_mu   (the dataset half of pred_fc.0, constant per call)
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                     z2 = fmaf(ux2[r * XS + v], w2[v], z2);
                 }
                 const float hv = (fmaxf(z1, 0.f) + fmaxf(z2, 0.f)) * 0.5f;
-                Hb[r * HS + c] = hv;
+                HbT[c * HT + r] = hv;
                 hmax = fmaxf(hmax, hv);
                 // r = 4k + q: tile k >> 3, row-in-tile r32 = 4 (k & 7) + q -> half k & 1, register q + 4 * ((k & 7) >> 1)
                 const int i = q + 4 * ((k & 7) >> 1);
@@ -255,98 +264,103 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     }
 
     auto id_xf = [](v4f a, int) { return a; };
-    // Adjacency mixing, one (graph, column) item per thread: the 8 rows of the column stay in registers and are written
-    // to U1 / U2 ONCE as split-pair fp16 rows (the five column-tile waves that read a row would otherwise each repeat
-    // the split).  The power-of-two scale must be known before the first value is written, so it comes from a bound:
-    // the producer of Hb noted max |Hb| in amaxv[ph]; A1 and A2 are row-normalised with non-negative entries, so
-    // |A H| <= max |H| (forward), and |A^T D| <= max |D| * (largest column sum of A1 / A2, colsum_max) (backward).
-    // two adjacent columns (c even) of one row: the hi halves are one dword, the lo halves the dword 8 halves on
-    auto put_split2 = [&](float *U, int row, int at, float v0, float v1, float sa) {
-        _Float16 h0, l0, h1, l1;
-        split16(v0, sa, h0, l0);
-        split16(v1, sa, h1, l1);
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        _Float16 *d = reinterpret_cast<_Float16 *>(U + row * HS) + at;
-        *reinterpret_cast<h2 *>(d) = h2{h0, h1};
-        *reinterpret_cast<h2 *>(d + 8) = h2{l0, l1};
-    };
-    static_assert(GH % 2 == 0 && HS % 2 == 0, "mixing items are column pairs");
-    typedef float f2v __attribute__((ext_vector_type(2)));
-    auto mix_fwd = [&](int ph) {   // U1 = A1 H, U2 = A2 H; one (graph, column pair) per thread
-        const float sa = pow2_scale(__uint_as_float(amaxv[ph]));
-        int t0 = tid;
-        asm volatile("" : "+v"(t0));       // the item's LDS addresses are computed here, not hoisted out of the layer loop (spills)
-#pragma unroll 1
-        for (int i = t0; i < G * (GH / 2); i += NT) {
-            const int g = i / (GH / 2), c = 2 * (i - g * (GH / 2));
-            const int at = (c >> 3) * 16 + (c & 7);          // split_at(c), in halves
-            f2v hv[N];
+    // Adjacency mixing on the matrix cores, one (column tile, row tile) job per wave like the layer GEMMs:
+    //   D[c][row] = sum_j X[j][c] B[row][j],   X = H (forward) or 1/2 dH . relu mask (backward), B = A1 / A2 or their transposes.
+    // B is block diagonal (8 x 8 per graph): of the 64 k only the 32 of the row tile's four graphs contribute, two k steps.
+    // A operand: lane (column c, k half) reads 8 consecutive rows of H^T (two ds_read_b128) and splits them with `sa_in`;
+    // B operand: lane (row, k half) holds its graph's adjacency row where the k half is its own graph, zeros elsewhere
+    // (entries in [0, 1], scale 1024).  A lane of the result holds one row and quads of consecutive columns, which are
+    // contiguous in the split-pair rows of U1 / U2: two 8-byte stores per quad.  `out_mul` turns the accumulator into the
+    // stored operand of the following GEMM (its scale over sa_in 1024, times the 1/2 of the backward pass).
+    static_assert(PRED_NW == PRED_NT * MT, "one (column tile, row tile) pair per wave");
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int my_nt = wv / MT, my_mt = wv - my_nt * MT;
+    const int ln = tid & 63, lr = ln & 31, lh = ln >> 5;
+    constexpr float ADJ_SCALE = 1024.0f;
+    auto mix_mfma = [&](const float *B1, const float *B2, float sa_in, float out_mul, const uint32_t *bl) {
+        const int cc = (my_nt * 32 + lr < GH) ? my_nt * 32 + lr : GH - 1;       // lanes past column 143: any valid address
+        const float *xp = HbT + cc * HT + my_mt * 32 + 8 * lh;
+        const int own = lr >> 3;                                                 // graph of this lane's row inside the tile
+        const float *b1p = B1 + ((my_mt * 4 + own) * N + (lr & 7)) * N, *b2p = B2 + ((my_mt * 4 + own) * N + (lr & 7)) * N;
+        uint32_t w0 = 0u, w1 = 0u;
+        if (bl) { w0 = bl[(my_mt * 2 + 0) * BW + cc]; w1 = bl[(my_mt * 2 + 1) * BW + cc]; }
+        f32x16 acc1, acc2;
 #pragma unroll
-            for (int j = 0; j < N; ++j) hv[j] = *reinterpret_cast<const f2v *>(Hb + (g * N + j) * HS + c);
+        for (int i = 0; i < 16; ++i) { acc1[i] = 0.f; acc2[i] = 0.f; }
+        auto split8 = [&](const v4f a, const v4f b, float sc, h8 &hi, h8 &lo) {
 #pragma unroll
-            for (int n = 0; n < N; ++n) {
-                float a1[N], a2[N];
-                load_row<N>(A1 + (g * N + n) * N, a1);
-                load_row<N>(A2 + (g * N + n) * N, a2);
-                float u1x = 0.f, u1y = 0.f, u2x = 0.f, u2y = 0.f;
+            for (int e = 0; e < 8; ++e) {
+                _Float16 h_, l_;
+                split16(e < 4 ? a[e] : b[e - 4], sc, h_, l_);
+                hi[e] = h_; lo[e] = l_;
+            }
+        };
+        auto masked = [&](const v4f a, uint32_t nib) {
+            return v4f{(nib & 1u) ? a.x : 0.f, (nib & 2u) ? a.y : 0.f, (nib & 4u) ? a.z : 0.f, (nib & 8u) ? a.w : 0.f};
+        };
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    u1x = fmaf(a1[j], hv[j].x, u1x); u1y = fmaf(a1[j], hv[j].y, u1y);
-                    u2x = fmaf(a2[j], hv[j].x, u2x); u2y = fmaf(a2[j], hv[j].y, u2y);
-                }
-                put_split2(U1, g * N + n, at, u1x, u1y, sa);
-                put_split2(U2, g * N + n, at, u2x, u2y, sa);
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const v4f x0 = *reinterpret_cast<const v4f *>(xp + 16 * s_), x1 = *reinterpret_cast<const v4f *>(xp + 16 * s_ + 4);
+            const bool mine = own == 2 * s_ + lh;
+            v4f p0 = {0.f, 0.f, 0.f, 0.f}, p1 = p0, q0 = p0, q1 = p0;
+            if (mine) {
+                p0 = *reinterpret_cast<const v4f *>(b1p); p1 = *reinterpret_cast<const v4f *>(b1p + 4);
+                q0 = *reinterpret_cast<const v4f *>(b2p); q1 = *reinterpret_cast<const v4f *>(b2p + 4);
+            }
+            h8 b1h, b1l, b2h, b2l;
+            split8(p0, p1, ADJ_SCALE, b1h, b1l);
+            split8(q0, q1, ADJ_SCALE, b2h, b2l);
+            if (bl) {
+                // rows 8 (2 s + lh) + e of the tile: e < 4 in the word of lane half 0 (bits 4 q + e), e >= 4 in that of half 1
+                const int q4 = 4 * (2 * s_ + lh);
+                h8 ah, al;
+                split8(masked(x0, (w0 >> q4) & 15u), masked(x1, (w1 >> q4) & 15u), sa_in, ah, al);
+                acc1 = mfma16(ah, b1h, acc1); acc1 = mfma16(ah, b1l, acc1); acc1 = mfma16(al, b1h, acc1);
+                split8(masked(x0, (w0 >> (16 + q4)) & 15u), masked(x1, (w1 >> (16 + q4)) & 15u), sa_in, ah, al);
+                acc2 = mfma16(ah, b2h, acc2); acc2 = mfma16(ah, b2l, acc2); acc2 = mfma16(al, b2h, acc2);
+            } else {
+                h8 ah, al;
+                split8(x0, x1, sa_in, ah, al);
+                acc1 = mfma16(ah, b1h, acc1); acc1 = mfma16(ah, b1l, acc1); acc1 = mfma16(al, b1h, acc1);
+                acc2 = mfma16(ah, b2h, acc2); acc2 = mfma16(ah, b2l, acc2); acc2 = mfma16(al, b2h, acc2);
             }
         }
+        // lane = row my_mt * 32 + lr; registers 4 q .. 4 q + 3 = columns my_nt * 32 + 8 q + 4 lh + (0 .. 3)
+        const int row = my_mt * 32 + lr;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = my_nt * 32 + 8 * q + 4 * lh;
+            if (c0 < GH) {
+                h4 h1_, l1_, h2_, l2_;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 a_, b_;
+                    split16(acc1[4 * q + e], out_mul, a_, b_); h1_[e] = a_; l1_[e] = b_;
+                    split16(acc2[4 * q + e], out_mul, a_, b_); h2_[e] = a_; l2_[e] = b_;
+                }
+                const int at = (c0 >> 3) * 16 + (c0 & 7);            // split_at(c0), in halves
+                _Float16 *d1 = reinterpret_cast<_Float16 *>(U1 + row * HS) + at, *d2 = reinterpret_cast<_Float16 *>(U2 + row * HS) + at;
+                *reinterpret_cast<h4 *>(d1) = h1_; *reinterpret_cast<h4 *>(d1 + 8) = l1_;
+                *reinterpret_cast<h4 *>(d2) = h2_; *reinterpret_cast<h4 *>(d2 + 8) = l2_;
+            }
+        }
+    };
+    // The power-of-two scale of the stored operand comes from a bound, the producer of H^T noted max |H| in amaxv[ph]:
+    // A1 and A2 are row-normalised with non-negative entries, so |A H| <= max |H| (forward), and
+    // |A^T D| <= max |D| * (largest column sum of A1 / A2, colsum_max) (backward).
+    auto mix_fwd = [&](int ph) {   // U1 = A1 H, U2 = A2 H
+        const float sa = pow2_scale(__uint_as_float(amaxv[ph]));
+        mix_mfma(A1, A2, sa, 1.0f / ADJ_SCALE, nullptr);
         return sa;
     };
-    // P1 = A1^T (1/2 dH . m1), P2 = A2^T (1/2 dH . m2) into U1, U2
-    auto mix_bwd = [&](int l, int ph) {
-        const uint32_t *bl = bits + (size_t)l * BL;
+    auto mix_bwd = [&](int l, int ph) {   // P1 = A1^T (1/2 dH . m1), P2 = A2^T (1/2 dH . m2) into U1, U2
+        const float sd = pow2_scale(__uint_as_float(amaxv[ph]));
         const float sa = pow2_scale(__uint_as_float(amaxv[ph]) * 0.5f * __uint_as_float(colsum_max));
-        int t0 = tid;
-        asm volatile("" : "+v"(t0));       // the item's LDS addresses are computed here, not hoisted out of the layer loop (spills)
-#pragma unroll 1
-        for (int i = t0; i < G * (GH / 2); i += NT) {
-            const int g = i / (GH / 2), c = 2 * (i - g * (GH / 2));
-            const int at = (c >> 3) * 16 + (c & 7);
-            // rows 8g .. 8g+7 = row tile g >> 2, rows-in-tile 8 (g & 3) + j: half j >> 2, register (j & 3) + 4 (g & 3)
-            const uint32_t bw0[2] = {bl[((g >> 2) * 2 + 0) * BW + c], bl[((g >> 2) * 2 + 1) * BW + c]};
-            const uint32_t bw1[2] = {bl[((g >> 2) * 2 + 0) * BW + c + 1], bl[((g >> 2) * 2 + 1) * BW + c + 1]};
-            float p1x[N], p1y[N], p2x[N], p2y[N];
-#pragma unroll
-            for (int n = 0; n < N; ++n) { p1x[n] = 0.f; p1y[n] = 0.f; p2x[n] = 0.f; p2y[n] = 0.f; }
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const int rj = g * N + j;
-                const f2v dh2 = *reinterpret_cast<const f2v *>(Hb + rj * HS + c);
-                const float dhx = dh2.x * 0.5f, dhy = dh2.y * 0.5f;
-                const int bi = (j & 3) + 4 * (g & 3);
-                const float d1x = ((bw0[j >> 2] >> bi) & 1u) ? dhx : 0.f, d2x = ((bw0[j >> 2] >> (16 + bi)) & 1u) ? dhx : 0.f;
-                const float d1y = ((bw1[j >> 2] >> bi) & 1u) ? dhy : 0.f, d2y = ((bw1[j >> 2] >> (16 + bi)) & 1u) ? dhy : 0.f;
-                float a1[N], a2[N];
-                load_row<N>(A1 + rj * N, a1);
-                load_row<N>(A2 + rj * N, a2);
-#pragma unroll
-                for (int n = 0; n < N; ++n) {
-                    p1x[n] = fmaf(a1[n], d1x, p1x[n]); p1y[n] = fmaf(a1[n], d1y, p1y[n]);
-                    p2x[n] = fmaf(a2[n], d2x, p2x[n]); p2y[n] = fmaf(a2[n], d2y, p2y[n]);
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < N; ++n) {
-                put_split2(U1, g * N + n, at, p1x[n], p1y[n], sa);
-                put_split2(U2, g * N + n, at, p2x[n], p2y[n], sa);
-            }
-        }
+        mix_mfma(A1T, A2T, sd, 0.5f * sa / (sd * ADJ_SCALE), bits + (size_t)l * BL);
         return sa;
     };
 
     // ---- layers 1 .. L-1 forward -----------------------------------------------------------------
-    static_assert(PRED_NW == PRED_NT * MT, "one (column tile, row tile) pair per wave in the layer GEMMs");
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int my_nt = wv / MT, my_mt = wv - my_nt * MT;
-    const int ln = tid & 63, lr = ln & 31, lh = ln >> 5;
     const float *u1p = U1 + (my_mt * 32 + lr) * HS + lh * (GH / 2), *u2p = U2 + (my_mt * 32 + lr) * HS + lh * (GH / 2);
     // B fragments of the wave's first tile (pinned issue point)
     auto prefetch_b = [&](const float *W, float (&b)[GH / 2]) {
@@ -370,11 +384,16 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             float hmax = 0.f;
             uint32_t w = 0u;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int row = my_mt * 32 + acc_row(i, lh);
-                w |= ((acc1[i] > 0.f ? 1u : 0u) << i) | ((acc2[i] > 0.f ? 1u : 0u) << (16 + i));
-                const float hv = (fmaxf(acc1[i], 0.f) + fmaxf(acc2[i], 0.f)) * 0.5f;
-                if (col < GH) { Hb[row * HS + col] = hv; hmax = fmaxf(hmax, hv); }
+            for (int q = 0; q < 4; ++q) {      // registers 4 q .. 4 q + 3 = rows my_mt * 32 + 8 q + 4 lh + (0 .. 3): one quad of H^T
+                v4f h4v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * q + e;
+                    w |= ((acc1[i] > 0.f ? 1u : 0u) << i) | ((acc2[i] > 0.f ? 1u : 0u) << (16 + i));
+                    h4v[e] = (fmaxf(acc1[i], 0.f) + fmaxf(acc2[i], 0.f)) * 0.5f;
+                    if (col < GH) hmax = fmaxf(hmax, h4v[e]);
+                }
+                if (col < GH) *reinterpret_cast<v4f *>(HbT + col * HT + my_mt * 32 + 8 * q + 4 * lh) = h4v;
             }
             bl[(my_mt * 2 + lh) * BW + col] = w;
             if (l + 1 < L) note_max(hmax, ph + 1);     // scale bound of the next layer's mixing
@@ -391,7 +410,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             const int g = i / GH, c = i - g * GH;
             float s = 0.f;
 #pragma unroll
-            for (int n = 0; n < N; ++n) s += Hb[(g * N + n) * HS + c];
+            for (int n = 0; n < N; ++n) s += HbT[c * HT + g * N + n];
             const int gg = (g0 + g < batch) ? g0 + g : 0;
             const float pv = s / (float)N + temb[(size_t)(tstride ? gg : 0) * GH + c];   // digcn_meta.py:19-22, :125
             U1[g * HS + c] = pv;
@@ -476,7 +495,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                         const float d = acc[i] / (float)N;
                         dmax = fmaxf(dmax, fabsf(d));
 #pragma unroll
-                        for (int n = 0; n < N; ++n) Hb[(g * N + n) * HS + col] = d;
+                        for (int n = 0; n < N; ++n) HbT[col * HT + g * N + n] = d;
                     }
                 }
                 note_max(dmax, ph + 1);    // max |dH_L|: scale bound of the first backward mixing
@@ -501,10 +520,14 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             float dmax = 0.f;
             if (col < GH) {
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const float d = acc1[i] + acc2[i];
-                    Hb[(my_mt * 32 + acc_row(i, lh)) * HS + col] = d;
-                    dmax = fmaxf(dmax, fabsf(d));
+                for (int q = 0; q < 4; ++q) {
+                    v4f d4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d4[e] = acc1[4 * q + e] + acc2[4 * q + e];
+                        dmax = fmaxf(dmax, fabsf(d4[e]));
+                    }
+                    *reinterpret_cast<v4f *>(HbT + col * HT + my_mt * 32 + 8 * q + 4 * lh) = d4;
                 }
             }
             note_max(dmax, ph + 1);        // scale bound of the next mixing (layer l - 1)
