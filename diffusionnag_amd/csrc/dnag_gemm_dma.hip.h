@@ -10,16 +10,18 @@
 //     k group l >> 4) of a 16x16x32 fragment reads one slot for hi and one for lo; both are conflict free;
 //   * a phased main loop.  A k tile (32 k) is staged as four half tiles of 128 rows x 128 B = 16 KB (A rows 0-127, B rows
 //     0-127, B rows 128-255, A rows 128-255), two k tiles of them in LDS (128 KB).  A wave owns a 64 x 32 piece of each
-//     quadrant (A half, B half) of the 256 x 256 block tile and works through the quadrants in four phases per k tile;
-//     a phase is a load segment (fragment reads of the half tile that is new to the phase, two DMA pieces, a counted
-//     vmcnt), a barrier, a compute segment (24 MFMAs), a barrier.  The two waves of a SIMD (w and w + 4) run one segment
-//     apart, so in every segment one of them feeds the matrix cores while the other reads LDS and issues DMA.  Every
-//     phase stages one half tile (16 pieces, 2 per wave), four phases = one k tile of time before it is read; the
-//     DMA stays in flight across the raw s_barriers and is retired by vmcnt(8) in the load segment of the phase BEFORE
-//     the one that reads it (the barriers between order the other waves' pieces); a half tile's slot is restaged two
-//     or three phases after its last read.  Measured on the way here (same box, final.linears.1 at B = 4096): with the
-//     DMA removed the loop ran at 93 % MFMA issue (3292 cycles per k tile of 3072), with it 4200-4900, whether the 64
-//     pieces of a k tile were issued as a burst, spread between the MFMAs, or staggered between the waves of a SIMD.
+//     quadrant (A half, B half) of the 256 x 256 block tile and works through the quadrants in two phases per k tile;
+//     a phase is a load segment (fragment reads of the half tiles new to the phase, four DMA pieces, a counted vmcnt), a
+//     raw s_barrier, a compute segment (48 MFMAs between an s_setprio pair: it keeps hipcc from moving them across the
+//     barriers), a raw s_barrier.  The two waves of a SIMD (w and w + 4: groups 0 and 1) run one segment apart, so in
+//     every segment one of them feeds the matrix cores while the other reads LDS and issues DMA.  The DMA stays in flight
+//     across the barriers (no fence) for at least one k tile and is retired by a counted vmcnt in the load segment of the
+//     phase BEFORE the one that reads it (the barriers between order the other waves' pieces); a half tile's slot is
+//     restaged two phases after its last read, one phase after for group 1, whose segments lie later.
+//     Measured on the way here (same box, final.linears.1 at B = 4096): with the DMA removed a one-barrier loop ran at
+//     93 % MFMA issue, with it 30-50 % slower whether the 64 pieces of a k tile were issued as a burst, spread between
+//     the MFMAs or staggered between the waves of a SIMD; a four-phase version of this loop (24 MFMAs per segment, eight
+//     barriers per k tile) was 1-2.5 % slower than this one; without the s_setprio pair or without the stagger +15 %.
 // Block tile 256 x 256 x 32, 8 waves (2 x 4), one workgroup per CU.
 // Included by dnag_lib.hip.
 #pragma once
@@ -29,9 +31,6 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16x(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-#ifndef X_WAIT
-#define X_WAIT "s_waitcnt vmcnt(8)"
-#endif
 struct DmaGeom {
     static constexpr int BM = 256, BN = 256, BK = 32, T = 512;
     static constexpr int ROWW = 32;                                   // dwords per staged row (32 k: 16 of hi, 16 of lo)
@@ -70,23 +69,26 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
     const int tm = wg / nbn, tn = wg - tm * nbn;
     const float out_inv = sc[0], sa_out = sc[1];
 
-    // ---- LDS-DMA staging: this wave fills rows 16 wave .. 16 wave + 15 of every half tile, 8 rows per instruction.
-    // Lane = (row in the piece, physical slot); the slot's content is planar slot p = ps ^ (row & 7), i.e. 16-byte chunk
-    // 2 (p & 3) + (p >> 2) of the row's 128 bytes in global memory (split-pair order: hi, lo per k group).
-    const int prow = lane >> 3, ps = lane & 7, pp = ps ^ prow;       // (16 wave + 8 q + prow) & 7 == prow
+    // ---- LDS-DMA staging: a half tile is staged by the four waves of ONE group, wave w4 of the group fills its rows
+    // 32 w4 .. 32 w4 + 31, 8 rows per instruction.  Lane = (row in the piece, physical slot); the slot's content is planar
+    // slot p = ps ^ (row & 7), i.e. 16-byte chunk 2 (p & 3) + (p >> 2) of the row's 128 bytes in global memory (split-pair
+    // order: hi, lo per k group).
+    const int prow = lane >> 3, ps = lane & 7, pp = ps ^ prow;       // (32 w4 + 8 q + prow) & 7 == prow
     const int chunk = 2 * (pp & 3) + (pp >> 2);
     // W is k-tile blocked ([k tile][row][32 dwords], kblock_rows), A too if A_KBLK, else row-major with pitch K
     const size_t a_row = A_KBLK ? ROWW : K, a_kt = A_KBLK ? (size_t)M * ROWW : Ge::BK, w_kt = (size_t)Nout * ROWW;
-    const float *ag = A + (size_t)(tm * BM + wave * 16 + prow) * a_row + chunk * 4;
-    const float *wgp = W + (size_t)(tn * BN + wave * 16 + prow) * ROWW + chunk * 4;
+    const int w4 = wave & 3;
+    const float *ag = A + (size_t)(tm * BM + w4 * 32 + prow) * a_row + chunk * 4;
+    const float *wgp = W + (size_t)(tn * BN + w4 * 32 + prow) * ROWW + chunk * 4;
     // half tile kinds in slot order: 0 = A rows 0-127, 1 = B rows 0-127, 2 = B rows 128-255, 3 = A rows 128-255
-    auto stage_half = [&](int kt, int kind) {
+    auto stage_half_grp = [&](int kt, int kind) {
         const bool isa = (kind == 0 || kind == 3);
         const size_t row = isa ? a_row : ROWW;
         const float *src = (isa ? ag : wgp) + ((kind >= 2) ? 128 * row : 0) + (size_t)kt * (isa ? a_kt : w_kt);
-        float *dst = smem + ((kt & 1) * 4 + kind) * HALF + wave * 16 * ROWW;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + 8 * row), (lptr_t)(dst + 8 * ROWW), 16, 0, 0);
+        float *dst = smem + ((kt & 1) * 4 + kind) * HALF + w4 * 32 * ROWW;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + q * 8 * row), (lptr_t)(dst + q * 8 * ROWW), 16, 0, 0);
     };
 
     f32x4 acc[2][2][4][2];          // [A half][B half][row tile][column tile]
@@ -122,9 +124,7 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
     };
     // 24 MFMAs of one quadrant; the three of one accumulator are seven others apart
     auto quadrant = [&](int h, int b) {
-#ifndef X_NOPRIO
         __builtin_amdgcn_s_setprio(1);
-#endif
         if constexpr (FUSE_V > 0) {          // D[n][m]: lane <-> batch row
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -152,103 +152,63 @@ __global__ __launch_bounds__(512, 1) void gemm_dma_kernel(const float *__restric
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[h][b][i][j] = mfma16x(al[i], bh[b][j], acc[h][b][i][j]);
         }
-#ifndef X_NOPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
     };
     // segment boundary: raw barrier, no fence (a fence would drain the DMA in flight)
 #define DNAG_BAR() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
-    // end of a load segment: stage half tile (skt, skind) if it exists, retire everything but the four youngest half tiles
-    // (eight pieces of this wave), barrier, wait for the segment's fragment reads
-#ifdef DNAG_GEMM_STAMPS
-    // stamps are only RECORDED inside a k tile (s_memtime into separate SGPRs, no use, so no lgkmcnt wait that would also
-    // drain the LDS reads) and turned into durations once per k tile, after its last barrier
-    long long st_prev = 0, st_raw[4][6], st_dur[4][6] = {};
-#define DNAG_ST(ph, k) do { st_raw[ph][k] = __builtin_readcyclecounter(); } while (0)
-#else
-#define DNAG_ST(ph, k)
-#endif
-#define DNAG_LOAD_END(skt, skind, ph)                                                        \
-    do {                                                                                     \
-        DNAG_ST(ph, 4);                                                                      \
-        if ((skt) < KT) { stage_half(skt, skind); DNAG_ST(ph, 5); asm volatile(X_WAIT ::: "memory"); } \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                \
-        DNAG_ST(ph, 0);                                                                      \
-        DNAG_BAR();                                                                          \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                   \
-        DNAG_ST(ph, 1);                                                                      \
-    } while (0)
-#define DNAG_PHASE_END(ph) do { DNAG_ST(ph, 2); DNAG_BAR(); DNAG_ST(ph, 3); } while (0)
-
     const int KT = K / Ge::BK;
 #ifdef DNAG_GEMM_TILE_STAMPS
     const long long tw0 = wall_clock64();
 #endif
-    // prologue: all of k tile 0 and the first two half tiles of k tile 1, in the order the phases read them; B0 of k tile 0
-    // is read here, B0 of every later k tile in phase 3 of the k tile before (fragment reads per phase: 8, 4, 8, 4)
-    stage_half(0, 1); stage_half(0, 0); stage_half(0, 2); stage_half(0, 3);
-    if (KT > 1) { stage_half(1, 1); stage_half(1, 0); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // Two phases per k tile (48 MFMAs per compute segment, four barriers per k tile): X = quadrants (A0, B0), (A0, B1) after
+    // reading B0, B1, A0; Y = (A1, B1), (A1, B0) after reading A1.  A half tile is staged by the four waves of one group
+    // (four pieces each), in the group's own load segments: group 0 stages B1 of k tile t + 1 in X(t) and A1 of t + 1 in
+    // Y(t); group 1, whose segments lie one later, may reuse a slot one phase earlier and stages B0 of t + 1 in X(t) and
+    // A0 of t + 2 in Y(t).  Every half tile is in flight for at least two phases (one k tile) and is retired, by the
+    // group that issued it, in the load segment of the phase before its first read: vmcnt(4) after the phase's own four
+    // pieces (group 1 has nothing to retire in X).
+    if (grp == 0) { stage_half_grp(0, 0); stage_half_grp(0, 1); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else {
+        stage_half_grp(0, 2); stage_half_grp(0, 3);
+        if (KT > 1) { stage_half_grp(1, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     DNAG_BAR();
 #ifdef DNAG_GEMM_TILE_STAMPS
     const long long tw1 = wall_clock64();
 #endif
-    read_b(0, 0);
-#ifndef X_NOSTAG
     if (grp == 1) DNAG_BAR();
-#endif
-#ifdef DNAG_GEMM_STAMPS
-    st_prev = __builtin_readcyclecounter();
-#endif
     for (int kt = 0; kt < KT; ++kt) {
         const int par = kt & 1;
-        // phase 0: quadrant (A0, B0); stages B1 of k tile kt + 1
-        read_a(par, 0);
-        DNAG_LOAD_END(kt + 1, 2, 0);
-        quadrant(0, 0);
-        DNAG_PHASE_END(0);
-        // phase 1: quadrant (A0, B1); stages A1 of k tile kt + 1
+        // phase X
+        read_b(par, 0);
         read_b(par, 1);
-        DNAG_LOAD_END(kt + 1, 3, 1);
+        read_a(par, 0);
+        if (grp == 0) {
+            if (kt + 1 < KT) { stage_half_grp(kt + 1, 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (kt + 1 < KT) stage_half_grp(kt + 1, 1);
+        DNAG_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        quadrant(0, 0);
         quadrant(0, 1);
-        DNAG_PHASE_END(1);
-        // phase 2: quadrant (A1, B0); stages B0 of k tile kt + 2 (B0 of kt was last read in phase 3 of kt - 1)
+        DNAG_BAR();
+        // phase Y
         read_a(par, 3);
-        DNAG_LOAD_END(kt + 2, 1, 2);
-        quadrant(1, 0);
-        DNAG_PHASE_END(2);
-        // phase 3: quadrant (A1, B1); reads B0 of k tile kt + 1 (retired in phase 2), stages A0 of k tile kt + 2
-        if (kt + 1 < KT) read_b(par ^ 1, 0);
-        DNAG_LOAD_END(kt + 2, 0, 3);
-        quadrant(1, 1);
-        DNAG_PHASE_END(3);
-#ifdef DNAG_GEMM_STAMPS
-        {
-            constexpr int order[6] = {4, 5, 0, 1, 2, 3};
-#pragma unroll
-            for (int ph = 0; ph < 4; ++ph)
-#pragma unroll
-                for (int q = 0; q < 6; ++q) {
-                    const int k = order[q];
-                    if (k == 5 && !((ph < 2 ? kt + 1 : kt + 2) < KT)) { continue; }
-                    st_dur[ph][k] += st_raw[ph][k] - st_prev;
-                    st_prev = st_raw[ph][k];
-                }
+        if (grp == 0) {
+            if (kt + 1 < KT) { stage_half_grp(kt + 1, 3); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (kt + 2 < KT) { stage_half_grp(kt + 2, 0); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#endif
+        DNAG_BAR();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        quadrant(1, 1);
+        quadrant(1, 0);
+        DNAG_BAR();
     }
-#ifndef X_NOSTAG
     if (grp == 0) DNAG_BAR();
-#endif
-#ifdef DNAG_GEMM_STAMPS
-    if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && (wave & 3) == 0)
-        for (int ph = 0; ph < 4; ++ph)
-            printf("gemm stamps block %d wave %d V %d phase %d: reads %lld dma %lld vmcnt %lld bar %lld mfma %lld bar %lld (cycles per k tile)\n", (int)blockIdx.x,
-                   wave, FUSE_V, ph, st_dur[ph][4] / KT, st_dur[ph][5] / KT, st_dur[ph][0] / KT, st_dur[ph][1] / KT, st_dur[ph][2] / KT, st_dur[ph][3] / KT);
-#endif
-#undef DNAG_PHASE_END
-#undef DNAG_ST
-#undef DNAG_LOAD_END
 #undef DNAG_BAR
     __syncthreads();
 #ifdef DNAG_GEMM_TILE_STAMPS
