@@ -304,6 +304,34 @@ def test_unconditional_b256_step_matches_oracle():
     close(r["rec_x_pred"][0], rec[0]["x_pred"], 5e-6, "x_pred")
 
 
+@pytest.mark.parametrize("B", [1, 3])
+def test_guided_sampler_on_a_tiny_batch_matches_oracle(B):
+    """Edge of the batch range: one graph (and three) in a workgroup built for eight, guided, three complete PC steps
+    against the oracle's loop (every kernel runs with dead rows; the Langevin step size is the mean over B graphs)."""
+    from oracle import dnag_oracle as O
+    S = 3
+    cfg = score_config(CateDims(), DEV)
+    sd = synthetic.cate_state_dict(CateDims(), seed=0)
+    sdp = synthetic.predictor_state_dict(PredictorDims(), seed=1)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3, conditional=True)
+    tape = synthetic.noise_tape(S, (B, 8, 7), 77 + B)
+    fn.noise_tape = {k_: v.to(DEV) for k_, v in tape.items()}
+    fn.max_steps, fn.record = S, True
+    mask = utils.aug_mask(utils.nb201_adj())[0]
+    task = synthetic.synthetic_task(10, 20, seed=2)
+    fn(make_score(CateDims(), 0), mask, make_pred(1), classifier_scale=100.0, task=task)
+    r = fn.last_record
+    rec = []
+    O.pc_sample(sd, O.VPSDE(0.1, 20.0, 1000), mask, tape, n_steps=S, pred_sd=sdp, D_mu=O.set_encode(sdp, task),
+                classifier_scale=100.0, record=rec)
+    for i in range(S):
+        close(r["rec_score_c"][i], rec[i]["score_c"], 2e-5, f"score_c[{i}]")
+        close(r["rec_cgrad_c"][i], rec[i]["cgrad_c"], 2e-5, f"cgrad_c[{i}]")
+        close(r["rec_x_corr"][i], rec[i]["x_corr"], 1e-5, f"x_corr[{i}]")
+        close(r["rec_x_pred"][i], rec[i]["x_pred"], 1e-5, f"x_pred[{i}]")
+
+
 def test_tape_run_is_reproducible_and_batch_size_independent_per_eval():
     """Same tape twice -> identical bits (fixed reduction orders, no atomics)."""
     g = golden("pc_uncond_nb201_n1000_first8")
