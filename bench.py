@@ -80,6 +80,25 @@ def predictor_cate_config(device):
                          num_sample=d.num_sample, graph_encoder=ge))
 
 
+def physical_cores():
+    """Distinct (package, core) pairs this process may run on (from /proc/cpuinfo and the affinity mask); None if unknown."""
+    try:
+        allowed = os.sched_getaffinity(0)
+        seen, cpu, phys = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k = k.strip()
+            if k == "processor":
+                cpu, phys = int(v), None
+            elif k == "physical id":
+                phys = int(v)
+            elif k == "core id" and cpu in allowed:
+                seen.add((phys, int(v)))
+        return len(seen) or None
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds=12.0):
     """The oracle (PyTorch-eager CPU restatement of the reference, validated against its golden vectors)
     timed on this box's host cores on a bounded sample of the same workload: guided NB201 PC steps
@@ -99,7 +118,7 @@ def cpu_baseline(seconds=12.0):
         O.pc_sample(sd, sde, mask, tape, n_steps=8, **kw)
         steps += 8
     dt = time.perf_counter() - t0
-    return {"value": B / (dt / steps * 1000.0), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": B / (dt / steps * 1000.0), "unit": "samples/s", "cores": torch.get_num_threads(), "physical_cores": physical_cores(), "kind": "port",
             "sample": f"{steps} guided PC steps (2 score evals + 2 guidance grads each) at B={B} in {dt:.1f} s, "
                       f"x1000 steps per trajectory"}
 

@@ -96,6 +96,9 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
 //                8 max|gamma| + max|beta| with affine, max_c (8 ||W_c||_2 + |b_c|) for a linear on a LayerNorm output
 //                (Cauchy-Schwarz, ||u||_2 <= 8; attention outputs are convex combinations of such values),
 //                max_c (||W_c||_1 amax_in + |b_c|) for a linear on a bounded input; ReLU / ELU do not raise a bound >= 1.
+//                Dropout: the sampling path runs in eval mode (models/utils.py:63-65); the training forward multiplies
+//                the attention probabilities and the FFN hidden by 1 / (1 - p) before they are split, and
+//                train_scales_kernel multiplies those two bounds by the same factor.
 // Networks with ordinary weights get 256 / 16 everywhere (the only values round 1 used); a checkpoint with large
 // weights gets smaller powers of two and keeps its accuracy relative to the magnitudes involved.
 // ---------------------------------------------------------------------------------------------

@@ -552,16 +552,22 @@ static int launch_gemm_t(const float *A, const float *W, const float *bias, floa
 
 static int launch_gemm(const float *A, const float *W, const float *bias, float *C, size_t M, int Nout, int K, bool timed,
                        size_t real_rows, hipStream_t st, const float *sc, const float *W3 = nullptr, int V = 0) {
-    int slot = -1;
+    // the event handles are copied out under the lock: dnag_timing_end may clear the vectors from another thread (an
+    // event destroyed between here and its record only fails that record)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (timed) {
         std::lock_guard<std::mutex> lk(g_tm_mu);
         if (g_tm.on) {
-            if (g_tm.seen % g_tm.every == 0 && g_tm.used < g_tm.max_samples) slot = g_tm.used++;
+            if (g_tm.seen % g_tm.every == 0 && g_tm.used < g_tm.max_samples) {
+                ev0 = g_tm.ev0[g_tm.used];
+                ev1 = g_tm.ev1[g_tm.used];
+                g_tm.used++;
+            }
             g_tm.seen++;
             g_tm.flops = 2.0 * (double)real_rows * (double)Nout * (double)K;
         }
     }
-    if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev0[slot], st));
+    if (ev0) HIP_TRY(hipEventRecord(ev0, st));
     // split-arithmetic fp16 MFMA GEMMs (dnag_gemm_dma.hip.h): final.linears.0 (K = F) reads the encoder's split-pair
     // concat and writes split-pair rows, both k-tile blocked; final.linears.1 (K = 2F, the timed one) reads those and
     // applies final.linears.2 in its epilogue.  Both weight matrices are k-tile blocked (kblock_rows at pack time).
@@ -583,7 +589,7 @@ static int launch_gemm(const float *A, const float *W, const float *bias, float 
         hipLaunchKernelGGL(k0, dim3(grid), dim3(Ge::T), Ge::lds_bytes, st, A, W, bias, C, (int)M, Nout, K, (const float *)nullptr, (float *)nullptr, sc);
     }
     LAUNCH_CHECK();
-    if (slot >= 0) HIP_TRY(hipEventRecord(g_tm.ev1[slot], st));
+    if (ev1) HIP_TRY(hipEventRecord(ev1, st));
     return 0;
 }
 
@@ -1201,7 +1207,7 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     HIP_TRY(cpy(e.f2_b, S + sl.f2_b, (size_t)V));
     HIP_TRY(cpy(e.pe, p->tables, (size_t)N * d));
     HIP_TRY(cpy(e.freq, p->tables + (size_t)N * d, (size_t)d / 2));
-    hipLaunchKernelGGL(train_scales_kernel, dim3(L), dim3(256), 0, st, S, sl, P, tl);
+    hipLaunchKernelGGL(train_scales_kernel, dim3(L), dim3(256), 0, st, S, sl, P, tl, drop ? 1.0f / (1.0f - p->dropout_p) : 1.0f);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(train_pack_layers_kernel, dim3(32, L), dim3(256), 0, st, S, sl, P, tl);
     LAUNCH_CHECK();

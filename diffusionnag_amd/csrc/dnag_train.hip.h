@@ -153,8 +153,10 @@ __device__ __forceinline__ void frag16_put(float *base, size_t K, size_t row, si
 
 // Power-of-two operand scales of one encoder layer (dnag_common.h "Operand scales", what cate_pack_impl derives on the
 // host), from the current parameters: grid (L), 256 threads; runs before train_pack_layers_kernel, which reads them.
+// `inv_keep` = 1 / (1 - p) of the training forward's dropout (1 without): the attention probabilities and the FFN hidden
+// are multiplied by it before they are split (transformer.py:19, :54), so the two activation bounds grow by that factor.
 __global__ __launch_bounds__(256) void train_scales_kernel(const float *__restrict__ S, const CateStateLayout sl,
-                                                           float *__restrict__ P, const TrainLayout tl) {
+                                                           float *__restrict__ P, const TrainLayout tl, const float inv_keep) {
     const int l = blockIdx.x, t = threadIdx.x;
     const int d = tl.enc.d, dff = tl.enc.dff;
     const float *SL = S + sl.layer0 + (size_t)l * sl.layer_stride;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void train_scales_kernel(const float *__restri
     if (t == 0) {
         const float sw_qkv = weight_scale(__uint_as_float(m[0])), sw_o = weight_scale(__uint_as_float(m[1]));
         const float sw_1 = weight_scale(__uint_as_float(m[2])), sw_2 = weight_scale(__uint_as_float(m[3]));
-        const float sa_o = act_scale(__uint_as_float(m[4])), sa_f2 = act_scale(__uint_as_float(m[5]));
+        const float sa_o = act_scale(__uint_as_float(m[4]) * inv_keep), sa_f2 = act_scale(__uint_as_float(m[5]) * inv_keep);
         SC[ENC_SC_INV_QKV] = 1.0f / (16.0f * sw_qkv);
         SC[ENC_SC_SA_O] = sa_o;
         SC[ENC_SC_INV_O] = 1.0f / (sa_o * sw_o);

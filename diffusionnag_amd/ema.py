@@ -46,10 +46,14 @@ class ExponentialMovingAverage:
             lib = _lib.load()
             a = _lib.OptimArgsC()
             a.n, a.flags = flat.numel(), _lib.OPTIM_EMA
-            a.params, a.shadow, a.ema_one_minus_decay = _lib.ptr(flat), _lib.ptr(self.flat_shadow(live)), omd
+            shadow = self.flat_shadow(live)
+            if shadow.numel() != flat.numel():
+                raise RuntimeError(f"EMA shadow holds {shadow.numel()} values, the parameters {flat.numel()}")
+            a.params, a.shadow, a.ema_one_minus_decay = _lib.ptr(flat), _lib.ptr(shadow), omd
             a.stream = _lib.current_stream(flat.device)
             with torch.cuda.device(flat.device):
                 _lib.check(lib.dnag_optim_step(C.byref(a)), "dnag_optim_step")
+            torch.autograd.graph.increment_version(self.shadow_params)     # raw-pointer write
             return
         with torch.no_grad():        # parameters that are not one flat device buffer (host-side use): multi-tensor plumbing
             diff = torch._foreach_sub(self.shadow_params, [p.detach() for p in live])
@@ -57,15 +61,17 @@ class ExponentialMovingAverage:
             torch._foreach_sub_(self.shadow_params, diff)
 
     def copy_to(self, parameters):
+        # in place on the parameters themselves (not on .data): their versions change, so the packed kernel-layout
+        # weights of the model are rebuilt before the next forward / sampling call
         with torch.no_grad():
-            torch._foreach_copy_([p.data for p in parameters if p.requires_grad], self.shadow_params)
+            torch._foreach_copy_([p for p in parameters if p.requires_grad], self.shadow_params)
 
     def store(self, parameters):
         self.collected_params = [p.clone() for p in parameters]
 
     def restore(self, parameters):
         with torch.no_grad():
-            torch._foreach_copy_([p.data for p in parameters], [c.data for c in self.collected_params])
+            torch._foreach_copy_(list(parameters), [c.data for c in self.collected_params])
 
     def state_dict(self):
         return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)

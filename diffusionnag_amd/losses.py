@@ -43,8 +43,13 @@ class FusedAdam:
             p.grad = None
 
     def _state(self, flat):
-        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
+        if self._m is not None and self._m.numel() != flat.numel():
+            raise RuntimeError("FusedAdam: the parameter list changed size after the first step")
+        if self._m is None:
             self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        elif self._m.device != flat.device:      # model moved after load_state_dict: the moments move with it (self.t is kept)
+            self._m, self._v = self._m.to(flat.device), self._v.to(flat.device)
+        if self._ws is None or self._ws.device != flat.device:
             self._ws = torch.empty(_lib.load().dnag_optim_workspace_bytes() // 4, dtype=torch.float32, device=flat.device)
             self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
 
@@ -52,9 +57,15 @@ class FusedAdam:
         lib = _lib.load()
         flat = flatten_(self.params)
         dev = _lib.require_device(flat)
+        missing = [p.grad is None for p in self.params]
+        if all(missing):       # torch.optim.Adam skips parameters without a gradient: nothing to do
+            return
+        if any(missing):
+            raise RuntimeError("FusedAdam updates one flat buffer: every parameter needs a gradient (torch.optim.Adam would "
+                               "skip the ones without; use it for partially frozen models)")
         grads = chain_view([p.grad for p in self.params])
         if grads is None:      # gradients that did not come from the fused training step: gather them (plumbing)
-            grads = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(torch.float32) for p in self.params])
+            grads = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in self.params])
         self._state(flat)
         g = self.param_groups[0]
         beta1, beta2 = g['betas']
@@ -72,12 +83,21 @@ class FusedAdam:
         a.grad_norm_out = _lib.ptr(self.last_grad_norm)
         if ema is not None:
             a.flags |= _lib.OPTIM_EMA
-            a.shadow = _lib.ptr(ema.flat_shadow(self.params))
+            shadow = ema.flat_shadow(self.params)
+            if shadow.numel() != flat.numel() or shadow.device != flat.device:
+                raise RuntimeError(f"EMA shadow holds {shadow.numel()} values on {shadow.device}, the optimiser "
+                                   f"{flat.numel()} on {flat.device}")
+            a.shadow = _lib.ptr(shadow)
             a.ema_one_minus_decay = ema.next_one_minus_decay()
         a.workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel() * 4
         a.stream = _lib.current_stream(dev)
         with torch.cuda.device(dev):
             _lib.check(lib.dnag_optim_step(C.byref(a)), "dnag_optim_step")
+        # The kernel wrote through raw pointers: tell torch, as an in-place op would.  Caches keyed on the parameters'
+        # versions (the kernel-layout weights of PackedModule.packed) follow from this.
+        torch.autograd.graph.increment_version(self.params)
+        if ema is not None:
+            torch.autograd.graph.increment_version(ema.shadow_params)
 
     # torch.optim.Adam's checkpoint format (reference utils.py:104-121 saves optimizer.state_dict())
     def state_dict(self):

@@ -244,7 +244,7 @@ size_t dnag_train_args_bytes(void);
  * Replaces get_sde_loss_fn_nas(...).loss_fn (losses.py:127-166, likelihood_weighting=False) followed by
  * loss.backward() (losses.py:222-223): the denoising-score-matching loss of one batch and its gradient
  * wrt every CATE parameter, with the network in training mode (dropout active, models/utils.py:66-68).
- * The optimiser step, gradient clipping and EMA (losses.py:22-36, models/ema.py) stay with the caller.
+ * The optimiser step, gradient clipping and EMA (losses.py:22-36, models/ema.py) are dnag_optim_step below.
  *
  * `params` / `grads` are flat fp32 device buffers in state_dict() order (dnag_cate_state_floats); `tables`
  * is the device copy of the constants dnag_cate_pack takes.  The random draws are inputs: z ~ N(0, 1)

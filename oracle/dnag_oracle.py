@@ -199,8 +199,8 @@ def _ln(sd: SD, prefix: str, x: Tensor) -> Tensor:
 
 def time_mlp(sd: SD, labels: Tensor, d_model: int) -> Tensor:
     """cate.py:155-157: timeEmb2(SiLU(timeEmb1(sincos(labels))))  (config nonlinearity 'swish')."""
-    e = timestep_embedding(labels, d_model)
-    return _lin(sd, "timeEmb2", F.silu(_lin(sd, "timeEmb1", e)))
+    e = timestep_embedding(labels, d_model).to(sd["timeEmb1.weight"].dtype)     # fp32 in the reference; a no-op unless the
+    return _lin(sd, "timeEmb2", F.silu(_lin(sd, "timeEmb1", e)))                # oracle is run in fp64 as a tie-breaker
 
 
 def _drop(x: Tensor, dropout: Optional[dict], key: str) -> Tensor:
