@@ -187,6 +187,10 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the short OFA and training side measurements (N = 1 only)")
     ap.add_argument("--sde-steps", type=int, default=1000, help="PC steps per trajectory (1000 = the full reverse SDE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--langevin", choices=["shard", "global"], default="shard",
+                    help="batch of the Langevin step size (reference sampling.py:249-252): 'shard' = every GPU's batch on its own "
+                         "(what one run of the reference per device does; no collective inside the trajectory), 'global' = all "
+                         "shards as ONE batch (one 8 KB RCCL all_gather per corrector update, bit-identical to the unsharded run)")
     ap.add_argument("--workload", choices=["nb201", "ofa", "train"], default="nb201",
                     help="nb201 = BASELINE configs[1] (the headline metric); ofa = configs[3] (20x9 graphs, MetaPredictorCATE), "
                          "a side measurement that never replaces the headline line; train = configs[2] (DSM training step, "
@@ -218,6 +222,7 @@ def bench_sampling(a, workload, steps, warmup):
     """One sampling measurement; returns the JSON line on rank 0 (None elsewhere)."""
 
     rank, world, local = D.init_from_env()
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()   # also a one-rank group (tests)
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     dev = torch.device("cuda", local)
@@ -248,6 +253,11 @@ def bench_sampling(a, workload, steps, warmup):
         fn.max_steps = a.sde_steps                               # debugging only: the reported metric needs 1000
     start, _ = D.shard_batch(total, rank, world)
     D.configure_sampler_shard(fn, start, N, V, seed=1234)
+    langevin = getattr(a, "langevin", "shard")
+    if langevin == "global":
+        if not grouped:
+            raise SystemExit("--langevin global needs a torch.distributed group (launch with torch.distributed.run)")
+        fn.langevin_batch = "global"
     torch.manual_seed(1000 + rank)                               # x0 is drawn on the CPU generator, like the reference
 
     def step():
@@ -256,7 +266,7 @@ def bench_sampling(a, workload, steps, warmup):
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if grouped:
             torch.distributed.barrier()
         torch.cuda.synchronize(dev)
 
@@ -275,7 +285,7 @@ def bench_sampling(a, workload, steps, warmup):
     _lib.check(lib.dnag_timing_read(C.byref(n_s), C.byref(mean_ms), C.byref(flops)), "dnag_timing_read")
     lib.dnag_timing_end()
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if grouped:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
     finite = bool(torch.isfinite(out).all())
@@ -301,7 +311,10 @@ def bench_sampling(a, workload, steps, warmup):
                                     "snr 0.16, classifier_scale 1e4, Floyd-closure mask, random-init weights (seeded), "
                                     "Philox noise on device"),
                        "batch_per_gpu": B, "global_batch": total, "pc_steps": a.sde_steps,
-                       "score_evals_per_sample": 2 * a.sde_steps, "parallelism": f"batch-shard x{world}"},
+                       "score_evals_per_sample": 2 * a.sde_steps, "parallelism": f"batch-shard x{world}",
+                       "langevin_batch": ("global: all shards as one batch, one all_gather of per-block norm sums per corrector update"
+                                          if langevin == "global" else
+                                          "per shard: every GPU's batch is its own Langevin batch, no collective inside the trajectory")},
             "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<ELU,false,V,true> (final.linears.1, M x 1536 x 1536, with final.linears.2 fused into its epilogue; fp32-accurate "
                                                     "hi/lo split on v_mfma_f32_16x16x32_f16, 3 MFMAs per product)",
                          "achieved": achieved, "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",

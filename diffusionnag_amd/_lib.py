@@ -33,6 +33,7 @@ EXPORTS = (
     "dnag_nb201_seen_reset", "dnag_nb201_validity",
     "dnag_train_workspace_bytes", "dnag_dropout_mask_bytes", "dnag_dropout_fill", "dnag_cate_dsm_step",
     "dnag_pred_forward_grad_noalloc", "dnag_optim_workspace_bytes", "dnag_optim_args_bytes", "dnag_optim_step",
+    "dnag_langevin_partials_floats",
 )
 
 
@@ -74,7 +75,13 @@ class PcArgsC(C.Structure):
         ("prod_w", C.c_int32),
         ("chain_x", _fp), ("chain_steps", C.c_int32), ("chain_keep", C.c_int32), ("chain_n", C.c_int32),
         ("chain_denoise", C.c_int32),
+        ("corrector_steps", C.c_int32),
+        ("langevin_exchange", C.c_void_p), ("langevin_user", C.c_void_p), ("langevin_local", _fp), ("langevin_global", _fp),
+        ("langevin_world", C.c_int32),
     ]
+
+
+LANGEVIN_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
 class TrainArgsC(C.Structure):
@@ -146,6 +153,8 @@ def load() -> C.CDLL:
     lib.dnag_pred_forward_grad_noalloc.argtypes = [C.POINTER(PredDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]
     lib.dnag_pc_sample.restype = i32
     lib.dnag_pc_sample.argtypes = [C.POINTER(PcArgsC)]
+    lib.dnag_langevin_partials_floats.restype = sz
+    lib.dnag_langevin_partials_floats.argtypes = [C.POINTER(CateDimsC), i32]
     lib.dnag_quantize.restype = i32
     lib.dnag_quantize.argtypes = [vp, vp, sz, vp]
     lib.dnag_timing_begin.restype = i32

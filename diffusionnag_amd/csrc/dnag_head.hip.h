@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
 // in the same fixed order, so all blocks derive the same step size without a grid barrier.
 // ---------------------------------------------------------------------------------------------
 struct CorrArgs {
-    const float *partials; int nparts;   // [2][nparts]
+    const float *partials; int nparts;   // [nseg][2][nparts / nseg]: one segment per rank (nseg = 1: this shard alone)
+    int nseg;
     int batch; size_t nelem;
     float snr, alpha;
     const float *gbuf; float *x;
@@ -377,7 +378,14 @@ __global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
     __shared__ float sh[256];
     const int tid = threadIdx.x;
     float sg = 0.f, sn = 0.f;
-    for (int i = tid; i < a.nparts; i += 256) { sg += a.partials[i]; sn += a.partials[a.nparts + i]; }
+    // block k of the (global) batch: segment k / seg, entry k % seg; the order of the sums depends on k alone, so a
+    // batch cut into equal shards reduces exactly like the whole batch
+    const int seg = a.nparts / a.nseg;
+    for (int i = tid; i < a.nparts; i += 256) {
+        const int s_ = i / seg, j = i - s_ * seg;
+        sg += a.partials[(size_t)s_ * 2 * seg + j];
+        sn += a.partials[(size_t)s_ * 2 * seg + seg + j];
+    }
     const float grad_norm = block_sum_256(sg, sh) / (float)a.batch;
     const float noise_norm = block_sum_256(sn, sh) / (float)a.batch;
     // step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha

@@ -458,6 +458,10 @@ static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int 
     return w;
 }
 
+extern "C" size_t dnag_langevin_partials_floats(const dnag_cate_dims *cd, int batch) {
+    if (!cd || batch < 1) return 0;
+    return 2 * (size_t)((batch + exit_gf(*cd) - 1) / exit_gf(*cd));
+}
 extern "C" size_t dnag_workspace_bytes(const dnag_cate_dims *cd, const dnag_pred_dims *pd, int batch, int n_steps) {
     if (!cd || batch < 1) return 0;
     return ws_layout(*cd, pd, batch, n_steps < 1 ? 1 : n_steps).total * sizeof(float);
@@ -920,6 +924,14 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
         return fail(DNAG_E_ARG, "chain_steps=%d chain_keep=%d chain_n=%d (need 1 <= steps <= chain_n, 1 <= keep <= batch, n_steps <= chain_n)",
                     p->chain_steps, p->chain_keep, chain_n);
     const dnag_cate_dims &cd = *p->cate_dims;
+    const int CS = p->corrector_steps > 0 ? p->corrector_steps : 1;
+    if (CS > 1024) return fail(DNAG_E_ARG, "corrector_steps=%d", p->corrector_steps);
+    if (p->langevin_exchange) {
+        if (!p->langevin_local || !p->langevin_global || p->langevin_world < 1)
+            return fail(DNAG_E_ARG, "langevin_exchange needs langevin_local, langevin_global and langevin_world >= 1");
+        if (p->batch % exit_gf(cd))
+            return fail(DNAG_E_ARG, "exact-global-batch Langevin mode: the shard holds %d graphs, not a multiple of %d", p->batch, exit_gf(cd));
+    }
     const CateLayout lay = cate_layout(cd);
     const WsLayout w = ws_layout(cd, p->pred_dims, p->batch, p->n_steps, p->predcate_dims);
     if (p->workspace_bytes < w.total * sizeof(float))
@@ -967,15 +979,17 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
 
     for (int i = 0; i < S; ++i) {
         const float *row = p->sched + (size_t)i * DNAG_SCHED_COLS;
-        // phase 0: corrector, phase 1: predictor; a None corrector / predictor evaluates nothing (sampling.py:216-224, :259-267)
-        for (int phase = p->corrector ? 0 : 1; phase < (p->predictor == DNAG_PREDICTOR_NONE ? 1 : 2); ++phase) {
-            const bool corr = phase == 0;
+        // sub-steps 0 .. CS-1: corrector updates (sampling.py:244, :283-293), sub-step CS: predictor; a None corrector /
+        // predictor evaluates nothing (sampling.py:216-224, :259-267)
+        for (int sub = p->corrector ? 0 : CS; sub < (p->predictor == DNAG_PREDICTOR_NONE ? CS : CS + 1); ++sub) {
+            const bool corr = sub < CS;
+            const int ci = i * CS + sub;          // index of this corrector update in the tape / the records
             const bool guide_now = guided && (p->guide_steps == nullptr || p->guide_steps[i] != 0);
             if (guide_now) {
                 if (guided_pc) {
                     if (int rc = run_predcate(pclay, p->predcate_packed, x, ws + w.temb_p + (size_t)i * pclay.enc.d, 0, p->mask, 0, nullptr, cgrad, B, ws + w.pc, pcw, st)) return rc;
                 } else if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, p->d_mu, nullptr, cgrad, B, st)) return rc;
-                float *rc_ = rec_at(corr ? p->rec_cgrad_c : p->rec_cgrad_p, i);
+                float *rc_ = corr ? rec_at(p->rec_cgrad_c, ci) : rec_at(p->rec_cgrad_p, i);
                 if (rc_) HIP_TRY(hipMemcpyAsync(rc_, cgrad, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
             if (int rc = run_score_body(cd, lay, p->cate_packed, x, ws + w.temb_s + (size_t)i * lay.d, 0, p->mask, 0, ws, w, nullptr, B, st)) return rc;
@@ -988,14 +1002,14 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             a.cgrad = guide_now ? cgrad : nullptr;
             a.cscale = (p->cscale_steps ? p->cscale_steps[i] : p->classifier_scale) * p->label_sign;
             a.wr_mode = p->weight_ratio; a.wr_p = p->weight_ratio_p; a.prod_w = p->prod_w;
-            a.gbuf = gbuf; a.partials = partials;
+            a.gbuf = gbuf; a.partials = p->langevin_exchange ? p->langevin_local : partials;
             a.x = x; a.x_mean = x_mean;
             a.sqrt_alpha = row[DNAG_SCHED_SQRTA]; a.G = row[DNAG_SCHED_G]; a.G2 = row[DNAG_SCHED_G2];
             const float *tape = corr ? p->noise_corr : p->noise_pred;
-            a.noise = tape ? tape + (size_t)i * nelem : nullptr;
-            a.seed = p->seed; a.stream_offset = p->stream_offset; a.draw = (uint32_t)(1 + 2 * i + (corr ? 0 : 1));
-            a.rec_score = rec_at(corr ? p->rec_score_c : p->rec_score_p, i);
-            a.rec_total = rec_at(corr ? p->rec_total_c : p->rec_total_p, i);
+            a.noise = tape ? tape + (size_t)(corr ? ci : i) * nelem : nullptr;
+            a.seed = p->seed; a.stream_offset = p->stream_offset; a.draw = (uint32_t)(1 + i * (CS + 1) + sub);
+            a.rec_score = corr ? rec_at(p->rec_score_c, ci) : rec_at(p->rec_score_p, i);
+            a.rec_total = corr ? rec_at(p->rec_total_c, ci) : rec_at(p->rec_total_p, i);
             a.rec_a = corr ? nullptr : rec_at(p->rec_x_mean, i);
             a.rec_b = corr ? nullptr : rec_at(p->rec_x_pred, i);
             a.parts = ws + w.h2; a.nparts = lay.Hd / SplitGeom::BN; a.part_stride = w.rows_pad * (size_t)lay.V;
@@ -1003,12 +1017,19 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             if (corr) {
                 CorrArgs c;
                 memset(&c, 0, sizeof(c));
-                c.partials = partials; c.nparts = w.nblk_exit; c.batch = B; c.nelem = nelem;
+                c.partials = partials; c.nparts = w.nblk_exit; c.nseg = 1; c.batch = B; c.nelem = nelem;
+                if (p->langevin_exchange) {
+                    // every rank's per-block sums, in rank order, reduced as one batch of world * B graphs would be
+                    if (int rc = p->langevin_exchange(p->langevin_user, p->stream))
+                        return fail(DNAG_E_ARG, "langevin_exchange callback failed with %d at PC step %d", rc, i);
+                    c.partials = p->langevin_global; c.nseg = p->langevin_world; c.nparts = w.nblk_exit * p->langevin_world;
+                    c.batch = B * p->langevin_world;
+                }
                 c.snr = p->snr; c.alpha = row[DNAG_SCHED_ALPHA];
                 c.gbuf = gbuf; c.x = x;
                 c.noise = a.noise; c.seed = a.seed; c.stream_offset = a.stream_offset; c.draw = a.draw;
-                c.rec_x = rec_at(p->rec_x_corr, i);
-                c.rec_step = p->rec_step_size ? p->rec_step_size + (size_t)i * 3 : nullptr;
+                c.rec_x = rec_at(p->rec_x_corr, ci);
+                c.rec_step = p->rec_step_size ? p->rec_step_size + (size_t)ci * 3 : nullptr;
                 const int grid = (int)((nelem + 255) / 256 < 2048 ? (nelem + 255) / 256 : 2048);
                 hipLaunchKernelGGL(corrector_update_kernel, dim3(grid), dim3(256), 0, st, c);
                 LAUNCH_CHECK();

@@ -4,10 +4,13 @@ The reference is single-device.  Graphs are independent 
 network, the surrogate and the predictor update, so the sample batch is cut into contiguous shards,
 one per rank, and every rank runs the full reverse SDE on its shard with replicated weights.  The
 only collective is the final gather of the ``[B/W, N, V]`` samples (RCCL over xGMI with the ``nccl``
-backend; ``gloo`` on CPU for tests).  Each shard is its own Langevin batch -- the step size
+backend; ``gloo`` on CPU for tests).  By default each shard is its own Langevin batch -- the step size
 (reference ``sampling.py:249-252``) is a mean over the shard, exactly what running the reference
-once per device would do.  Philox noise is keyed by the global element index, so the noise a graph
-sees does not depend on the number of ranks.
+once per device would do.  ``sampler.langevin_batch = 'global'`` selects the exact-global-batch mode
+(SURVEY.md 8e): one small all-gather of per-block norm sums per corrector update (``LangevinExchange``),
+after which every rank reduces the same list in the same order, so the step size is bit-identical to that
+of ONE batch holding all the graphs.  Philox noise is keyed by the global element index, so the noise a
+graph sees does not depend on the number of ranks.
 """
 
 from __future__ import annotations
@@ -75,3 +78,38 @@ def gather_samples(x_local: torch.Tensor, total: int) -> torch.Tensor:
     dist.all_gather_into_tensor(out, pad.contiguous())
     out = out.view((world, cmax) + tuple(x_local.shape[1:]))
     return torch.cat([out[r, : counts[r]] for r in range(world)], dim=0)
+
+
+class LangevinExchange:
+    """The per-corrector-update exchange of the exact-global-batch Langevin mode (``include/dnag.h``,
+    ``dnag_pc_args.langevin_exchange``).  ``local`` receives this shard's per-block sums of ``||grad_b||`` and
+    ``||noise_b||`` (``[2][blocks]``, written by the exit kernel); ``__call__`` all-gathers every rank's ``local``
+    into ``global_`` ``[world][2][blocks]`` in rank order, on the caller's stream.  With the ``nccl`` backend this is
+    one RCCL ``all_gather`` of 8 KB per rank (8192 graphs) enqueued behind the exit kernel; other backends (``gloo``:
+    tests) stage through the host."""
+
+    def __init__(self, n_floats: int, device: torch.device):
+        if not dist.is_initialized():
+            raise RuntimeError("langevin_batch='global' needs an initialised torch.distributed process group")
+        self.world = dist.get_world_size()
+        self.local = torch.zeros(n_floats, dtype=torch.float32, device=device)
+        self.global_ = torch.zeros(self.world * n_floats, dtype=torch.float32, device=device)
+        self.calls = 0
+        self.error: BaseException | None = None
+
+    def __call__(self) -> None:
+        self.calls += 1
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(self.global_, self.local)      # ordered after the exit kernel on the current stream
+            return
+        host = self.local.cpu()                                           # synchronises with the stream
+        out = torch.empty(self.world * host.numel(), dtype=torch.float32)
+        dist.all_gather_into_tensor(out, host)
+        self.global_.copy_(out)
+
+
+def gather_partials(local: torch.Tensor) -> torch.Tensor:
+    """What ``LangevinExchange`` does, for tensors on any device: every rank's ``local`` in rank order."""
+    out = torch.empty(dist.get_world_size() * local.numel(), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out

@@ -132,7 +132,11 @@ class _PCSampler:
     few attributes for tests and benchmarks: ``noise_tape`` (dict of device tensors ``x0 [B,N,V]``,
     ``corrector [S,B,N,V]``, ``predictor [S,B,N,V]`` consumed in the reference's RNG order),
     ``max_steps`` (run only the first steps of the time grid), ``record`` (keep per-step tensors in
-    ``last_record``), ``seed`` / ``stream_offset`` (Philox key and first element index of this shard)."""
+    ``last_record``), ``seed`` / ``stream_offset`` (Philox key and first element index of this shard),
+    ``langevin_batch`` (``'shard'``: the Langevin step size of ``sampling.py:249-252`` is a mean over this process's
+    batch, the default; ``'global'``: over the batches of all ranks of the ``torch.distributed`` group, exchanged per
+    corrector update, ``distributed.LangevinExchange``).  With ``n_steps_each = c > 1`` the corrector tape and the
+    corrector records hold ``S * c`` entries (entry ``i * c + k`` for update ``k`` of PC step ``i``)."""
 
     def __init__(self, sde, shape, predictor, corrector, inverse_scaler, snr, n_steps, probability_flow, continuous,
                  denoise, eps, device, noise):
@@ -146,8 +150,8 @@ class _PCSampler:
             raise NotImplementedError("probability_flow=True is not built")
         if not continuous:
             raise NotImplementedError("only continuous=True is supported (SURVEY.md 5.2-6)")
-        if n_steps != 1 and corrector.enabled:
-            raise NotImplementedError("n_steps_each != 1 is not built (every shipped config uses 1)")
+        if int(n_steps) != n_steps or n_steps < 1:
+            raise ValueError(f"n_steps_each={n_steps!r}: expected a positive integer")
         if noise not in ("philox", "torch"):
             raise ValueError(f"config.sampling.noise={noise!r}: expected 'philox' or 'torch'")
         self.sde, self.shape, self.corrector, self.predictor = sde, tuple(shape), corrector, predictor
@@ -159,6 +163,8 @@ class _PCSampler:
         self.last_record: Optional[dict] = None
         self.seed = 0
         self.stream_offset = 0
+        self.langevin_batch = "shard"
+        self.last_exchange = None
         self.weighting: Optional[dict] = None
         self.last_chain: Optional[torch.Tensor] = None
         self._ws = Workspace()
@@ -245,6 +251,8 @@ class _PCSampler:
         args.sched = sched.ctypes.data
         args.snr = float(self.snr)
         args.corrector = int(self.corrector.enabled)
+        CS = int(self.n_steps)                                       # corrector updates per PC step (sampling.py:244)
+        args.corrector_steps = CS
         args.predictor = int(self.predictor.kind)
         args.score_mode = int(self.sde.score_mode)
         args.prior_scale = float(self.sde.prior_scale)
@@ -254,11 +262,12 @@ class _PCSampler:
             x0 = self.sde.prior_sampling(self.shape).to(dev)         # CPU generator, then H2D (sampling.py:436)
             if self.noise == "torch":
                 # the reference draws eps then z with randn_like on the device generator, step by step
-                nc = torch.empty(S, B, N, V, device=dev)
+                nc = torch.empty(S * CS, B, N, V, device=dev)
                 npd = torch.empty(S, B, N, V, device=dev)
                 for i in range(S):
                     if self.corrector.enabled:
-                        nc[i] = torch.randn_like(x0)
+                        for k in range(CS):
+                            nc[i * CS + k] = torch.randn_like(x0)
                     if self.predictor.kind != _lib.PREDICTOR_NONE:
                         npd[i] = torch.randn_like(x0)
                 tape = {"x0": x0, "corrector": nc, "predictor": npd}
@@ -272,7 +281,7 @@ class _PCSampler:
         if nc is not None:
             nc = nc.to(dev, torch.float32).contiguous()
             npd = npd.to(dev, torch.float32).contiguous()
-            if nc.shape[0] < S or npd.shape[0] < S or tuple(nc.shape[1:]) != (B, N, V):
+            if nc.shape[0] < S * CS or npd.shape[0] < S or tuple(nc.shape[1:]) != (B, N, V):
                 raise ValueError("noise_tape is shorter than the number of steps or has the wrong shape")
         keep += [x0, nc, npd]
         args.x0, args.noise_corr, args.noise_pred = _lib.ptr(x0), _lib.ptr(nc), _lib.ptr(npd)
@@ -297,8 +306,9 @@ class _PCSampler:
             names = ["rec_score_c", "rec_total_c", "rec_x_corr", "rec_score_p", "rec_total_p", "rec_x_mean", "rec_x_pred"]
             if classifier is not None:
                 names += ["rec_cgrad_c", "rec_cgrad_p"]
-            rec = {n: torch.zeros(S, B, N, V, dtype=torch.float32, device=dev) for n in names}
-            rec["rec_step_size"] = torch.zeros(S, 3, dtype=torch.float32, device=dev)
+            per_corr = ("rec_score_c", "rec_total_c", "rec_x_corr", "rec_cgrad_c")
+            rec = {n: torch.zeros(S * CS if n in per_corr else S, B, N, V, dtype=torch.float32, device=dev) for n in names}
+            rec["rec_step_size"] = torch.zeros(S * CS, 3, dtype=torch.float32, device=dev)
             for n, t in rec.items():
                 setattr(args, n, _lib.ptr(t))
         if isinstance(classifier, MetaPredictorCATE):
@@ -308,9 +318,31 @@ class _PCSampler:
         ws = self._ws.get(nbytes, dev)
         args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         args.stream = _lib.current_stream(dev)
+        exch = cb = None
+        if self.langevin_batch == "global" and self.corrector.enabled:
+            from .distributed import LangevinExchange
+            exch = LangevinExchange(lib.dnag_langevin_partials_floats(C.byref(cd), B), dev)
+
+            def _exchange(_user, _stream):          # called by dnag_pc_sample once per corrector update, on this thread
+                try:
+                    exch()
+                    return 0
+                except BaseException as e:          # no exception crosses the C ABI
+                    exch.error = e
+                    return -1
+            cb = _lib.LANGEVIN_EXCHANGE_FN(_exchange)
+            args.langevin_exchange = C.cast(cb, C.c_void_p)
+            args.langevin_local, args.langevin_global = _lib.ptr(exch.local), _lib.ptr(exch.global_)
+            args.langevin_world = exch.world
+        elif self.langevin_batch not in ("shard", "global"):
+            raise ValueError(f"langevin_batch={self.langevin_batch!r}: expected 'shard' or 'global'")
         with torch.cuda.device(dev):
             rc = lib.dnag_pc_sample(C.byref(args))
+        if exch is not None and exch.error is not None:
+            raise RuntimeError("the Langevin exchange (torch.distributed all_gather) failed inside dnag_pc_sample") from exch.error
         _lib.check(rc, "dnag_pc_sample")
+        self.last_exchange = exch
+        del cb
         if classifier is not None:
             classifier.sample_state = False                          # sampling.py:576
         self.last_record = rec

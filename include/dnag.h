@@ -166,6 +166,8 @@ int dnag_predcate_forward_grad(const dnag_predcate_dims *d, const float *packed,
 #define DNAG_SCORE_VP 0     /* score = -model / std  (models/utils.py:103) */
 #define DNAG_SCORE_VE 1     /* score = model         (models/utils.py:116-117) */
 
+typedef int (*dnag_langevin_exchange_fn)(void *user, void *stream);   /* see dnag_pc_args.langevin_exchange */
+
 typedef struct dnag_pc_args {
     /* networks */
     const dnag_cate_dims *cate_dims;
@@ -232,7 +234,29 @@ typedef struct dnag_pc_args {
     int32_t chain_keep;
     int32_t chain_n;
     int32_t chain_denoise;
+    /* n_steps_each of the reference's configs (sampling.py:244 `for i in range(n_steps)`, :283-293): corrector updates
+     * per PC step, each with a score evaluation and a noise draw of its own.  0 means 1.  With c = corrector_steps the
+     * corrector tape and the corrector records (rec_score_c, rec_total_c, rec_cgrad_c, rec_x_corr, rec_step_size) hold
+     * n_steps * c entries, entry i * c + k for update k of PC step i; Philox draw indices are 1 + i (c + 1) + k for the
+     * corrector updates and 1 + i (c + 1) + c for the predictor (c = 1: the numbering of earlier versions). */
+    int32_t corrector_steps;
+    /* Exact-global-batch Langevin step size for a batch sharded over several processes ("optional").
+     * The step size of sampling.py:249-252 uses batch means of ||grad_b|| and ||noise_b||; by default every shard is its
+     * own batch.  With langevin_exchange set, each corrector update (i) writes this shard's per-block sums to
+     * langevin_local [dnag_langevin_partials_floats(cate_dims, batch)], (ii) calls
+     *     langevin_exchange(langevin_user, stream)      -- host callback, returns 0 on success
+     * which must enqueue, on `stream`, an all-gather of every rank's langevin_local into langevin_global
+     * [langevin_world][that many floats] in rank order (RCCL all_gather; 8 KB per rank at 8192 graphs), and (iii) reduces
+     * langevin_global in the fixed order a single batch of langevin_world * batch graphs would use: the step size is then
+     * bit-identical to the unsharded run's.  All shards must hold the same number of graphs, a multiple of 8 (NAS-Bench-201)
+     * or 3 (OFA).  NULL: per-shard batch means, no callback. */
+    dnag_langevin_exchange_fn langevin_exchange;
+    void *langevin_user;
+    float *langevin_local;             /* device */
+    float *langevin_global;            /* device */
+    int32_t langevin_world;
 } dnag_pc_args;
+size_t dnag_langevin_partials_floats(const dnag_cate_dims *cd, int batch);
 
 int dnag_pc_sample(const dnag_pc_args *args);
 /* sizeof(dnag_pc_args) / sizeof(dnag_train_args) as this library was built: a binding checks its own struct against

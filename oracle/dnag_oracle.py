@@ -428,8 +428,12 @@ def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3,
               n_steps: Optional[int] = None, pred_sd: Optional[SD] = None, D_mu: Optional[Tensor] = None,
               classifier_scale: float = 0.0, labels: str = "max", record: Optional[list] = None,
               model_kw: Optional[dict] = None, predictor: str = "reverse_diffusion", corrector: str = "langevin",
-              weighting: Optional[dict] = None, chain: Optional[dict] = None) -> Tensor:
+              weighting: Optional[dict] = None, chain: Optional[dict] = None, n_steps_each: int = 1) -> Tensor:
     """Predictor-corrector loop with injected noise (sampling.py:424-445 / :534-577).
+
+    ``n_steps_each`` = c: corrector updates per PC step (sampling.py:244); the corrector tape then holds ``S * c``
+    entries (entry ``i * c + k``) and a record gains ``corr`` = the list of the c updates' dicts (the flat keys
+    ``score_c`` ... ``x_corr`` describe the last one).
 
     ``chain`` = {'number_chain_steps': n, 'keep_chain': k, 'denoise': bool} restates the MobileNetV3 sampler's chain
     recording (MobileNetV3/sampling.py:980-988, :1030-1034): after PC step i the first k graphs of
@@ -496,16 +500,19 @@ def pc_sample(score_sd: SD, sde, mask: Tensor, tape: dict, *, eps: float = 1e-3,
             if corrector == "langevin":
                 # -- LangevinCorrector.update_fn, sampling.py:232-256
                 alpha = sde.langevin_alpha(vec_t)
-                grad, s1, cg1 = total_grad(x, vec_t)
-                noise = tape["corrector"][i]
-                grad_norm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
-                noise_norm = torch.norm(noise.reshape(B, -1), dim=-1).mean()
-                step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
-                x_mean = x + step_size[:, None, None] * grad
-                x = x_mean + torch.sqrt(step_size * 2)[:, None, None] * noise
-                if rec is not None:
-                    rec.update(score_c=s1, cgrad_c=cg1, total_c=grad, grad_norm=grad_norm, noise_norm=noise_norm,
-                               step_size=step_size[0].clone(), x_corr=x.clone())
+                for k in range(n_steps_each):                                   # :244
+                    grad, s1, cg1 = total_grad(x, vec_t)
+                    noise = tape["corrector"][i * n_steps_each + k]
+                    grad_norm = torch.norm(grad.reshape(B, -1), dim=-1).mean()
+                    noise_norm = torch.norm(noise.reshape(B, -1), dim=-1).mean()
+                    step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
+                    x_mean = x + step_size[:, None, None] * grad
+                    x = x_mean + torch.sqrt(step_size * 2)[:, None, None] * noise
+                    if rec is not None:
+                        one = dict(score_c=s1, cgrad_c=cg1, total_c=grad, grad_norm=grad_norm, noise_norm=noise_norm,
+                                   step_size=step_size[0].clone(), x_corr=x.clone())
+                        rec.update(one)
+                        rec.setdefault("corr", []).append(one)
             else:
                 assert corrector == "none"
                 x_mean = x

@@ -724,6 +724,44 @@ def test_pc_sampler_variants_golden(name):
 
 
 
+@pytest.mark.parametrize("name", ["pc_guided_nb201_nsteps2_n1000_first6", "pc_guided_nb201_nsteps2_contractive_n40"])
+def test_pc_two_corrector_updates_per_step_golden(name):
+    """config.sampling.n_steps_each = 2: two Langevin updates (score evaluation, noise draw and step size each) per PC
+    step, as the reference loops them (sampling.py:244); goldens from the reference (tests/golden/make_golden_nsteps.py)."""
+    g = golden(name)
+    CS, S, B = int(g["n_steps_each"]), int(g["n_run"]), int(g["B"])
+    cfg = score_config(CateDims(), DEV)
+    cfg.sampling["n_steps_each"] = CS
+    model = make_score(CateDims(), int(g["seed"]), preset=str(g["preset"]))
+    sde = sde_lib.VPSDE(0.1, 20.0, int(g["sde_N"]))
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), float(g["eps"]), conditional=True)
+    tape = synthetic.noise_tape(S * CS, (B, 8, 7), int(g["tape_seed"]))
+    fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
+    fn.max_steps, fn.record = S, True
+    final = fn(model, torch.from_numpy(g["mask"]), make_pred(1), classifier_scale=float(g["classifier_scale"]),
+               task=synthetic.synthetic_task(10, 20, seed=2))
+    r = fn.last_record
+    assert r["rec_score_c"].shape[0] == S * CS and r["rec_step_size"].shape[0] == S * CS and r["rec_score_p"].shape[0] == S
+    first = "first" in name
+    tol_x, tol_s = (5e-6, 1e-5) if first else (2e-4, 2e-4)
+    for i in (range(S) if first else (0, 1, S // 2, S - 1)):
+        for k in range(CS):
+            close(r["rec_score_c"][i * CS + k], g["score_c"][i * CS + k], tol_s, f"score_c[{i}.{k}]")
+            close(r["rec_cgrad_c"][i * CS + k], g["cgrad_c"][i * CS + k], tol_s, f"cgrad_c[{i}.{k}]")
+        close(r["rec_x_corr"][i * CS + CS - 1], g["x_corr_last"][i], tol_x, f"x_corr[{i}]")
+        close(r["rec_score_p"][i], g["score_p"][i], tol_s, f"score_p[{i}]")
+        close(r["rec_x_mean"][i], g["x_mean"][i], tol_x, f"x_mean[{i}]")
+        close(r["rec_x_pred"][i], g["x_pred"][i], tol_x, f"x_pred[{i}]")
+    if "final" in g:
+        close(final, g["final"], 2e-4, "final")
+        q = np.stack(utils.quantize(final))
+        assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
+    # the unconditional closure reports the reference's function-evaluation count (sampling.py:445)
+    fn_u = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), float(g["eps"]))
+    fn_u.max_steps = 1
+    assert fn_u(model, torch.from_numpy(g["mask"]).unsqueeze(0))[1] == sde.N * (CS + 1)
+
+
 @pytest.mark.parametrize("B", [1000, 4096])
 def test_score_evaluation_repeats_are_bitwise_identical(B):
     """Race screen of the head GEMMs' barrier / vmcnt structure (csrc/dnag_gemm_dma.hip.h: LDS-DMA in flight across raw

@@ -2,7 +2,9 @@
 draws on the device equals its rows of ONE global Philox stream (keyed by the global element index), whichever rank
 draws it, and the final gather runs through RCCL (a one-rank `nccl` group proves the library loads and the device path
 of all_gather_into_tensor works).  The per-evaluation parity of an 8192-graph shard against the oracle is in
-tests/test_gpu_parity.py::test_full_batch_guided_steps_match_oracle_on_a_slice."""
+tests/test_gpu_parity.py::test_full_batch_guided_steps_match_oracle.  The exact-global-batch Langevin mode (SURVEY.md 8e,
+"optional") is run by two processes sharing this GPU and compared bit for bit with the unsharded batch, and bench.py's
+multi-GPU path (barrier, MAX all_reduce of the time, gather, JSON line) runs once through a one-rank `nccl` group."""
 
 import os
 
@@ -66,5 +68,102 @@ def test_gather_runs_through_rccl_on_a_one_rank_group():
         torch.cuda.synchronize()
         assert out.shape == x.shape and out.data_ptr() != x.data_ptr() and torch.equal(out, x)
         assert dist.get_backend() == "nccl"
+    finally:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# exact-global-batch Langevin mode: two shards = the unsharded batch, bit for bit
+# ------------------------------------------------------------------------------------------------
+GB, GS = 48, 3          # graphs of the whole batch, PC steps
+
+
+def _guided_run(B, tape, offset, mode):
+    from diffusionnag_amd import digcn_meta as _dm  # noqa: F401
+    from diffusionnag_amd.specs import PredictorDims
+    from tests.helpers import predictor_config
+    cfg = score_config(CateDims(), DEV)
+    model = mutils.create_model(cfg)
+    model.load_state_dict(synthetic.cate_state_dict(CateDims(), seed=0))
+    clf = mutils.create_model(predictor_config(PredictorDims(), DEV))
+    clf.load_state_dict(synthetic.predictor_state_dict(PredictorDims(), seed=1))
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), 1e-3, conditional=True)
+    fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
+    fn.max_steps, fn.record = GS, True
+    fn.stream_offset = offset * 56
+    fn.langevin_batch = mode
+    out = fn(model.eval(), utils.aug_mask(utils.nb201_adj())[0], clf.eval(), classifier_scale=10000.0,
+             task=synthetic.synthetic_task(10, 20, seed=2))
+    r = fn.last_record
+    return dict(out=out.cpu(), step=r["rec_step_size"].cpu(), x_corr=r["rec_x_corr"].cpu(), x_pred=r["rec_x_pred"].cpu(),
+                calls=(fn.last_exchange.calls if fn.last_exchange is not None else 0))
+
+
+def _shard_worker(rank, world, port, path):
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        tape = synthetic.noise_tape(GS, (GB, 8, 7), 91)
+        lo, n = D.shard_batch(GB, rank, world)
+        mine = {k: (v[lo:lo + n] if k == "x0" else v[:, lo:lo + n]).contiguous() for k, v in tape.items()}
+        res = _guided_run(n, mine, lo, "global")
+        torch.save(res, os.path.join(path, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_shards_reproduce_the_single_batch_step_size(tmp_path):
+    """Two processes (gloo between them, both on this GPU) sample the two halves of a 48-graph batch in the
+    exact-global-batch mode: every corrector update exchanges the per-block norm sums (dnag_pc_args.langevin_exchange)
+    and reduces them in the order of the whole batch, so the step sizes -- and with them every state -- carry the same
+    bits as ONE process sampling all 48 graphs; in the default per-shard mode they differ."""
+    import socket
+    import torch.multiprocessing as mp
+    tape = synthetic.noise_tape(GS, (GB, 8, 7), 91)
+    whole = _guided_run(GB, tape, 0, "shard")                   # one batch: its own mean IS the global mean
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    for r in range(2):
+        assert parts[r]["calls"] == GS
+        assert torch.equal(parts[r]["step"], whole["step"]), f"rank {r}: step sizes differ from the unsharded batch"
+    for key in ("x_corr", "x_pred"):
+        assert torch.equal(torch.cat([parts[0][key], parts[1][key]], dim=1), whole[key]), key
+    assert torch.equal(torch.cat([parts[0]["out"], parts[1]["out"]]), whole["out"])
+    # the default mode: the first shard alone is its own Langevin batch
+    half = {k: (v[:GB // 2] if k == "x0" else v[:, :GB // 2]).contiguous() for k, v in tape.items()}
+    alone = _guided_run(GB // 2, half, 0, "shard")
+    assert not torch.equal(alone["step"], whole["step"])
+
+
+def test_bench_sampling_runs_through_a_one_rank_nccl_group(capsys):
+    """bench.py's --gpus N path on one GPU: the barrier, the MAX all_reduce of the time, the RCCL gather of the samples
+    and the JSON line, with one 8192-graph shard (BASELINE configs[4]) and two PC steps; then once more in the
+    exact-global-batch Langevin mode, whose per-update all_gather then runs through RCCL on the device."""
+    import argparse
+    import torch.distributed as dist
+    import bench
+    assert not dist.is_initialized()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29519", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        lines = {}
+        for mode in ("shard", "global"):
+            a = argparse.Namespace(gpus=1, steps=1, warmup=1, batch_per_gpu=SHARD, no_extra=True, sde_steps=2,
+                                   no_cpu_baseline=True, workload="nb201", langevin=mode)
+            line = bench.bench_sampling(a, "nb201", 1, 1)
+            assert line is not None and line["n_gpus"] == 1 and line["outputs_finite"]
+            assert line["config"]["global_batch"] == SHARD and line["config"]["pc_steps"] == 2
+            assert line["config"]["langevin_batch"].startswith("global" if mode == "global" else "per shard")
+            assert line["value"] > 0 and line["roofline"]["launches_timed"] >= 1
+            import json
+            json.dumps(line)
+            lines[mode] = line
     finally:
         dist.destroy_process_group()

@@ -424,6 +424,70 @@ def test_gather_world_size_2_gloo(tmp_path):
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
+_WORKER_LANGEVIN = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ["DNAG_REPO"])
+from diffusionnag_amd import distributed as D
+rank, world, local = D.init_from_env("gloo")
+# per-block sums of ||grad_b|| and ||noise_b|| of a 64-block batch (8 graphs per block), as the exit kernel writes
+# them: [2][blocks]; each rank holds its contiguous half
+rs = np.random.RandomState(3)
+gn, nn = rs.uniform(1, 1e4, 64).astype(np.float32), rs.uniform(50, 70, 64).astype(np.float32)
+nb = 64 // world
+local_p = torch.from_numpy(np.concatenate([gn[rank * nb:(rank + 1) * nb], nn[rank * nb:(rank + 1) * nb]]))
+glob = D.gather_partials(local_p)                               # [world][2][nb], rank order
+ex = D.LangevinExchange(2 * nb, torch.device("cpu"))            # the object dnag_pc_sample's callback drives
+ex.local.copy_(local_p)
+ex()
+assert torch.equal(ex.global_, glob) and ex.calls == 1
+
+
+def reduce_like_kernel(parts, nseg, batch):
+    # corrector_update_kernel (csrc/dnag_head.hip.h): thread t sums blocks t, t + 256, ... in order, then a pairwise tree
+    seg = parts.numel() // (2 * nseg)
+    p = parts.view(nseg, 2, seg)
+    out = []
+    for which in (0, 1):
+        flat = p[:, which, :].reshape(-1)                        # block k of the whole batch = segment k // seg, entry k % seg
+        lanes = np.zeros(256, np.float32)
+        for k in range(flat.numel()):
+            lanes[k % 256] = np.float32(lanes[k % 256] + np.float32(flat[k]))
+        s = 128
+        while s > 0:
+            lanes[:s] = (lanes[:s] + lanes[s:2 * s]).astype(np.float32)
+            s >>= 1
+        out.append(np.float32(lanes[0]) / np.float32(batch))
+    return out
+
+
+whole = torch.from_numpy(np.concatenate([gn, nn]))              # the unsharded batch's buffer: [1][2][64]
+a = reduce_like_kernel(whole, 1, 512)
+b = reduce_like_kernel(glob, world, 512)
+assert a[0] == b[0] and a[1] == b[1], (a, b)                     # bit for bit
+mine = reduce_like_kernel(local_p, 1, 512 // world)             # the per-shard mode differs (its own batch mean)
+assert mine[0] != a[0]
+sys.stdout.write(f"rank {rank} ok\n"); sys.stdout.flush()
+"""
+
+
+def test_langevin_exchange_world_size_2_gloo(tmp_path):
+    """Exact-global-batch Langevin mode: two shards exchange their per-block norm sums and reduce the
+    gathered list in the kernel's fixed order -- the same bits as the unsharded batch.  (The kernels' side of it is
+    tests/test_gpu_shard.py::test_two_shards_reproduce_the_single_batch_step_size.)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = tmp_path / "worker_langevin.py"
+    script.write_text(_WORKER_LANGEVIN)
+    env = dict(os.environ, DNAG_REPO=REPO, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
 # ----------------------------------------------------------------------------------------------------
 # DSM training step: host logic (the kernels are covered by tests/test_gpu_train.py)
 # ----------------------------------------------------------------------------------------------------

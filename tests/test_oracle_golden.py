@@ -107,6 +107,33 @@ def test_pc_full_trajectory_contractive(golden, name, guided):
     assert torch.equal(O.quantize(final.clone()), O.quantize(T(g["final"]).clone()))
 
 
+@pytest.mark.parametrize("name", ["pc_guided_nb201_nsteps2_n1000_first6", "pc_guided_nb201_nsteps2_contractive_n40"])
+def test_pc_two_corrector_updates_per_step(golden, name):
+    """n_steps_each = 2 (sampling.py:244): goldens from the reference's own loop (tests/golden/make_golden_nsteps.py)."""
+    g = golden(name)
+    CS, S, B = int(g["n_steps_each"]), int(g["n_run"]), int(g["B"])
+    sd = synthetic.cate_state_dict(CateDims(), seed=int(g["seed"]), preset=str(g["preset"]))
+    sdp = synthetic.predictor_state_dict(PredictorDims(), seed=1)
+    tape = synthetic.noise_tape(S * CS, (B, 8, 7), int(g["tape_seed"]))
+    rec = []
+    final = O.pc_sample(sd, O.VPSDE(0.1, 20.0, int(g["sde_N"])), T(g["mask"]), tape, eps=float(g["eps"]), snr=float(g["snr"]),
+                        n_steps=S, record=rec, pred_sd=sdp, D_mu=O.set_encode(sdp, synthetic.synthetic_task(10, 20, seed=2)),
+                        classifier_scale=float(g["classifier_scale"]), n_steps_each=CS)
+    first = "first" in name
+    tol = 2e-4
+    for i in (range(S) if first else (0, 1, S // 2, S - 1)):
+        assert len(rec[i]["corr"]) == CS
+        for k in range(CS):
+            close(rec[i]["corr"][k]["score_c"], g["score_c"][i * CS + k], 0, tol * np.abs(g["score_c"][i * CS + k]).max())
+            close(rec[i]["corr"][k]["cgrad_c"], g["cgrad_c"][i * CS + k], 0, 1e-3 * np.abs(g["cgrad_c"][i * CS + k]).max())
+        close(rec[i]["x_corr"], g["x_corr_last"][i], 0, tol * np.abs(g["x_corr_last"][i]).max())
+        close(rec[i]["score_p"], g["score_p"][i], 0, tol * np.abs(g["score_p"][i]).max())
+        close(rec[i]["x_pred"], g["x_pred"][i], 0, tol * np.abs(g["x_pred"][i]).max())
+    if "final" in g:
+        close(final, g["final"], 0, 1e-4 * np.abs(g["final"]).max())
+        assert torch.equal(O.quantize(final.clone()), O.quantize(T(g["final"]).clone()))
+
+
 def test_linspace_and_index_edges():
     sde = O.VPSDE(0.1, 20.0, 1000)
     ts = O.timesteps(sde, 1e-3)
