@@ -33,7 +33,7 @@ EXPORTS = (
     "dnag_nb201_seen_reset", "dnag_nb201_validity",
     "dnag_train_workspace_bytes", "dnag_dropout_mask_bytes", "dnag_dropout_fill", "dnag_cate_dsm_step",
     "dnag_pred_forward_grad_noalloc", "dnag_optim_workspace_bytes", "dnag_optim_args_bytes", "dnag_optim_step",
-    "dnag_langevin_partials_floats",
+    "dnag_langevin_partials_floats", "dnag_pred_workspace_bytes",
 )
 
 
@@ -153,6 +153,8 @@ def load() -> C.CDLL:
     lib.dnag_pred_forward_grad_noalloc.argtypes = [C.POINTER(PredDimsC), vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]
     lib.dnag_pc_sample.restype = i32
     lib.dnag_pc_sample.argtypes = [C.POINTER(PcArgsC)]
+    lib.dnag_pred_workspace_bytes.restype = sz
+    lib.dnag_pred_workspace_bytes.argtypes = [C.POINTER(PredDimsC), i32]
     lib.dnag_langevin_partials_floats.restype = sz
     lib.dnag_langevin_partials_floats.argtypes = [C.POINTER(CateDimsC), i32]
     lib.dnag_quantize.restype = i32

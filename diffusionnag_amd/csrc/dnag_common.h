@@ -114,6 +114,16 @@ static inline __host__ __device__ float split_pow2_scale(float bound, int kmax) 
     return ldexpf(1.0f, k);
 }
 static inline __host__ __device__ float weight_scale(float amax) { return split_pow2_scale(amax, 8); }
+// power of two s with s * bound in [512, 1024) (1 for bound = 0): the run-time operand scale (pow2_scale below), also
+// evaluated on the host for bounds that follow from the weights
+static inline __host__ __device__ float pow2_scale_of(float bound) {
+    if (!(bound > 0.f)) return 1.0f;
+    int e;
+    frexpf(bound, &e);
+    int k = 10 - e;
+    k = k > 40 ? 40 : (k < -40 ? -40 : k);
+    return ldexpf(1.0f, k);
+}
 static inline __host__ __device__ float act_scale(float bound) { return split_pow2_scale(bound, 4); }
 
 // per-layer table at l_sc
@@ -172,6 +182,8 @@ static inline void frag16_pack(const float *W, size_t rows, size_t K, size_t ld,
 //   gcn l: w1b/w2b = fragment-major W[in][out] (backward: dH_l = P W^T sums over `out`),
 //          w1f/w2f = fragment-major W^T[out][in] (forward, l >= 1);
 //   fc1f = fragment-major fc1 [lh][g] (a = fc1 p), fc1b = fragment-major fc1^T [g][lh] (dp = fc1^T da).
+// fp16 hi/lo fragments only (frag16_pack, no fp32 twin): w1f0 / w2f0 = gcn.0 W^T [g][V -> 16] (layer 0 forward as one
+// 32x32x16 step), p0f = arch half of pred_fc.0 [hs][lh] (tanh layer), p0b = its transpose [lh][hs -> hs16] (da = W0a^T dpre).
 // ---------------------------------------------------------------------------------------------
 #define DNAG_MAX_GCN 8
 struct PredLayout {
@@ -184,7 +196,12 @@ struct PredLayout {
     size_t p0_at;                 // transposed arch part [lh][hs]
     size_t p2_w, p2_b;            // pred_fc.2 [hs], [1]
     size_t freq;                  // [g/2]
-    size_t wsc;                   // 1 / sw of the split-arithmetic matrices: [2 l + {0: W1_l, 1: W2_l}], [2 L]: fc1
+    size_t wsc;                   // 1 / sw of the split-arithmetic matrices: [2 l + {0: W1_l, 1: W2_l}], [2 L]: fc1, [2 L + 1]: pred_fc.0
+    size_t w1f0, w2f0, p0f, p0b;  // fp16 hi/lo fragments (see above)
+    size_t mixs;                  // [l][w][4]: power-of-two scale of the mixing's A operand (the raw accumulator of the GEMM before it)
+                                  // and its reciprocal over 1024, forward then backward: a BOUND from the weights alone, since the
+                                  // GEMM's own A operand is always scaled to below 1024: |acc| <= 1024 sw max_c ||W_c||_1
+    int hs16;                     // hs rounded up to a multiple of 16 (K of the da product)
     size_t delta16;               // P + delta16 + (offset of w1b .. fc1b): the same fragment-major matrices as fp16 hi/lo
                                   // fragments scaled by 256 (frag16_pack) for the split-arithmetic MFMAs
     size_t total;
@@ -217,9 +234,15 @@ static inline __host__ __device__ PredLayout pred_layout(const dnag_pred_dims &c
     y.p2_w = o; o += align4(hs);
     y.p2_b = o; o += 4;
     y.freq = o; o += align4(g / 2);
-    y.wsc = o; o += align4(2 * DNAG_MAX_GCN + 1);
+    y.wsc = o; o += align4(2 * DNAG_MAX_GCN + 2);
     y.delta16 = o - y.w1b[0];
     o += (y.fc1b + frag_floats(g, lh)) - y.w1b[0];
+    y.hs16 = (int)((hs + 15) / 16 * 16);
+    y.mixs = o; o += 8 * DNAG_MAX_GCN;
+    y.w1f0 = o; o += frag_floats(g, 16);
+    y.w2f0 = o; o += frag_floats(g, 16);
+    y.p0f = o; o += frag_floats(hs, lh);
+    y.p0b = o; o += frag_floats(lh, (size_t)y.hs16);
     y.total = o;
     return y;
 }
@@ -306,14 +329,7 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) { return __builti
 
 // power of two s with s * amax in [512, 1024) (1 for amax = 0; capped so that products of two scales stay finite):
 // operand scale of the split-arithmetic MFMAs when the magnitude of an operand is only known at run time
-__device__ __forceinline__ float pow2_scale(float amax) {
-    if (!(amax > 0.f)) return 1.0f;
-    int e;
-    frexpf(amax, &e);
-    int k = 10 - e;
-    k = k > 40 ? 40 : (k < -40 ? -40 : k);
-    return ldexpf(1.0f, k);
-}
+__device__ __forceinline__ float pow2_scale(float amax) { return pow2_scale_of(amax); }
 
 // a * b rounded to fp32 and NOT fused into a following addition: hipcc contracts a product into its consumer by default
 // (-ffp-contract=fast), through __fmul_rn / __fadd_rn and through `#pragma clang fp contract(off)` alike (both tried:

@@ -24,11 +24,12 @@
 #include "dnag_common.h"
 #include "dnag_encoder.hip.h"
 
-#ifndef ENC8_PK
-// Two queries per thread on scalar fp32 instructions.  Built with -DENC8_PK the pair rides on v_pk_fma_f32 / v_pk_mul_f32
-// instead (half the instructions); that build is bit-exact with one workgroup per CU but returns wrong values in
-// lanes 32-63 of random graphs once two workgroups share a CU (two waves per SIMD; tests/micro/enc_cmp.py, round 2),
-// with every barrier and wait in place and the same thread mapping as this build -- not used until that is understood.
+// Two queries per thread as scalar pairs; the compiler's SLP pass turns most of these pairs into v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32 with op_sel broadcasts on its own (244 packed instructions in the production ISA).
+// Round 2 also carried a hand-packed variant (float2 ext vectors, -DENC8_PK) that was bit-exact at one workgroup per CU
+// and wrong in lanes 32-63 at two; its ISA was diffed against this build in round 3 (profiles/r03_enc8_pk_isa.md: same
+// barriers, waits and register budget, no spills; it differs in which softmax steps ride on packed adds behind
+// v_exp_f32 / v_rcp_f32 results), no cause could be named from the ISA, and the variant was deleted.
 struct v2f {
     float x, y;
     __device__ __forceinline__ v2f operator*(v2f o) const { return v2f{x * o.x, y * o.y}; }
@@ -37,11 +38,6 @@ struct v2f {
 };
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 __device__ __forceinline__ v2f pk_max(v2f a, v2f b) { return v2f{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
-#else
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f pk_max(v2f a, v2f b) { return __builtin_elementwise_max(a, b); }
-#endif
 
 struct Enc8Geom {
     static constexpr int N = 8, G = 8, R = 64, D = 64, H = 8, DK = 8, DFF = 128;
@@ -275,10 +271,6 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                     q[e] = v2f{a.x, b.x}; q[e + 1] = v2f{a.y, b.y}; q[e + 2] = v2f{a.z, b.z}; q[e + 3] = v2f{a.w, b.w};
                 }
             }
-#ifdef ENC8_PK
-            float rs_dk = 1.0f / sqrtf((float)DK);
-            asm volatile("" : "+v"(rs_dk));          // experiment: keep the packed multiplier out of the scalar registers
-#endif
             v2f s[N];
             v2f mx = {-3.0e38f, -3.0e38f};
             const float *mrow = maskb + (g * N + 2 * qp) * N;
@@ -294,11 +286,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                     acc = pk_fma(q[e + 2], v2f{k4.z, k4.z}, acc);
                     acc = pk_fma(q[e + 3], v2f{k4.w, k4.w}, acc);
                 }
-#ifdef ENC8_PK
-                acc = acc * v2f{rs_dk, rs_dk};
-#else
                 acc = acc * (1.0f / sqrtf((float)DK));
-#endif
                 if (mrow[j] == 0.f) acc.x = -1e9f;          // transformer.py:16
                 if (mrow[N + j] == 0.f) acc.y = -1e9f;
                 s[j] = acc;

@@ -264,7 +264,21 @@ extern "C" int dnag_pred_pack(const dnag_pred_dims *c, const float *s, const flo
             const float *W = s + o; o += in * g;   // [in][g]
             const float sw = weight_scale(amax_of(W, in * g));
             out[y.wsc + 2 * l + w] = 1.0f / sw;
-            if (l == 0) memcpy(out + (w ? y.w2_0 : y.w1_0), W, in * g * sizeof(float));
+            {   // bounds of the GEMM accumulators that feed the adjacency mixing (PredLayout::mixs)
+                double col1 = 0.0, row1 = 0.0;
+                for (size_t k = 0; k < g; ++k) { double a = 0.0; for (size_t i = 0; i < in; ++i) a += fabs((double)W[i * g + k]); col1 = fmax(col1, a); }
+                for (size_t i = 0; i < in; ++i) { double a = 0.0; for (size_t k = 0; k < g; ++k) a += fabs((double)W[i * g + k]); row1 = fmax(row1, a); }
+                float *ms = out + y.mixs + (2 * l + w) * 4;
+                const float sf = pow2_scale_of((float)(1024.0 * sw * col1 * 1.0001)), sb = pow2_scale_of((float)(1024.0 * sw * row1 * 1.0001));
+                ms[0] = sf; ms[1] = 1.0f / (sf * 1024.0f); ms[2] = sb; ms[3] = 1.0f / (sb * 1024.0f);
+            }
+            if (l == 0) {
+                memcpy(out + (w ? y.w2_0 : y.w1_0), W, in * g * sizeof(float));
+                std::vector<float> t16(g * 16, 0.f);            // W^T [g][V -> 16]: layer 0 forward, K = 16
+                for (size_t i = 0; i < in; ++i)
+                    for (size_t k = 0; k < g; ++k) t16[k * 16 + i] = W[i * g + k];
+                frag16_pack(t16.data(), g, 16, 16, out + (w ? y.w2f0 : y.w1f0), sw);
+            }
             frag_pack(W, in, g, g, out + (w ? y.w2b[l] : y.w1b[l]));
             frag16_pack(W, in, g, g, out + y.delta16 + (w ? y.w2b[l] : y.w1b[l]), sw);
             if (l > 0) {
@@ -295,6 +309,15 @@ extern "C" int dnag_pred_pack(const dnag_pred_dims *c, const float *s, const flo
         memcpy(out + y.p0_w, W, hs * (nz + lh) * sizeof(float));
         for (size_t j = 0; j < hs; ++j)
             for (size_t a = 0; a < lh; ++a) out[y.p0_at + a * hs + j] = W[j * (nz + lh) + nz + a];
+        // the arch half W0a [hs][lh] and its transpose [lh][hs16] as fp16 hi/lo fragments
+        const size_t hs16 = (size_t)y.hs16;
+        std::vector<float> wa(hs * lh), wt(lh * hs16, 0.f);
+        for (size_t j = 0; j < hs; ++j)
+            for (size_t a = 0; a < lh; ++a) { wa[j * lh + a] = W[j * (nz + lh) + nz + a]; wt[a * hs16 + j] = wa[j * lh + a]; }
+        const float sw = weight_scale(amax_of(wa.data(), hs * lh));
+        out[y.wsc + 2 * y.L + 1] = 1.0f / sw;
+        frag16_pack(wa.data(), hs, lh, lh, out + y.p0f, sw);
+        frag16_pack(wt.data(), lh, hs16, hs16, out + y.p0b, sw);
     }
     memcpy(out + y.p0_b, s + o, hs * sizeof(float)); o += hs;
     memcpy(out + y.p2_w, s + o, hs * sizeof(float)); o += hs;
@@ -388,7 +411,7 @@ extern "C" int dnag_predcate_pack(const dnag_predcate_dims *c, const float *s, c
 // ---------------------------------------------------------------------------------------------
 struct WsLayout {
     size_t rows, rows_pad;
-    size_t labels, temb_s, temb_p, concat, h1, h2, cgrad, gbuf, x, x_mean, partials, pc, total;   // float offsets
+    size_t labels, temb_s, temb_p, c0, concat, h1, h2, cgrad, gbuf, x, x_mean, partials, pc, total;   // float offsets
     int nblk_exit;
 };
 
@@ -444,6 +467,7 @@ static WsLayout ws_layout(const dnag_cate_dims &c, const dnag_pred_dims *p, int 
     w.labels = take(nt);
     w.temb_s = take(nt * c.d_model);
     w.temb_p = take(p ? nt * p->gcn_hidden : pc ? nt * pc->d_model : 0);
+    w.c0 = take(p ? (size_t)p->hs : 0);
     w.concat = take(w.rows_pad * F);
     w.h1 = take(w.rows_pad * Hd);
     w.h2 = take(w.rows_pad * Hd);
@@ -673,15 +697,22 @@ static int launch_exit(const dnag_cate_dims &c, const CateLayout &lay, const flo
     return 0;
 }
 
+// c0 [hs] = the dataset half of pred_fc.0, once per call (the set-encoder's D_mu is constant over a sampling call)
+static int launch_pred_c0(const PredLayout &lay, const float *P, const float *d_mu, float *c0, hipStream_t st) {
+    hipLaunchKernelGGL(pred_c0_kernel, dim3(lay.hs), dim3(64), 0, st, P, lay, d_mu, c0);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 static int launch_predictor(const PredLayout &lay, const float *P, const float *x, const float *temb, int tstride,
-                            const float *mask, int mstride, const float *d_mu, float *y, float *grad, int batch, hipStream_t st) {
+                            const float *mask, int mstride, const float *c0, float *y, float *grad, int batch, hipStream_t st) {
     typedef PredGeom<8, 7> Ge;
     const size_t lds = Ge::lds_bytes(lay.hs, lay.L);
     auto kern = predictor_kernel<8, 7>;
     static LdsAttr attr;
     if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
     const int grid = (batch + Ge::G - 1) / Ge::G;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, d_mu, y, grad, batch);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(PRED_NW * 64), lds, st, P, lay, x, temb, tstride, mask, mstride, c0, y, grad, batch);
     LAUNCH_CHECK();
     return 0;
 }
@@ -724,6 +755,12 @@ extern "C" int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, c
     return 0;
 }
 
+// workspace of dnag_pred_forward_grad: time embeddings [rows][144] (rows = batch, or 1 for a shared time), then c0 [hs]
+extern "C" size_t dnag_pred_workspace_bytes(const dnag_pred_dims *d, int batch) {
+    if (!d || batch < 1) return 0;
+    return (up((size_t)batch * d->gcn_hidden, 64) + up((size_t)d->hs, 64)) * sizeof(float);
+}
+
 extern "C" int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *packed, const float *x, const float *time_cond,
                                       int time_stride, const float *mask, int mask_stride, const float *d_mu, float *y,
                                       float *grad, int batch, void *workspace, size_t workspace_bytes, void *stream) {
@@ -732,12 +769,13 @@ extern "C" int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *pack
     if (batch < 1) return fail(DNAG_E_ARG, "batch=%d", batch);
     const PredLayout lay = pred_layout(*d);
     const size_t nt = time_stride ? batch : 1;
-    if (workspace_bytes < nt * lay.g * sizeof(float))
-        return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, nt * lay.g * sizeof(float));
+    const size_t need = dnag_pred_workspace_bytes(d, time_stride ? batch : 1);
+    if (workspace_bytes < need) return fail(DNAG_E_WORKSPACE, "workspace %zu bytes < %zu needed", workspace_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    float *temb = (float *)workspace;
+    float *temb = (float *)workspace, *c0 = temb + up(nt * lay.g, 64);
     if (int rc = launch_time_embed(time_cond, (int)nt, lay.g, packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, temb, st)) return rc;
-    return launch_predictor(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, d_mu, y, grad, batch, st);
+    if (int rc = launch_pred_c0(lay, packed, d_mu, c0, st)) return rc;
+    return launch_predictor(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, c0, y, grad, batch, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -747,7 +785,7 @@ extern "C" int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *pack
 // hipGetSymbolAddress, once per device, and only that pointer is ever handed to a kernel.
 // ---------------------------------------------------------------------------------------------
 #define NOALLOC_MAX_BATCH DNAG_NOALLOC_MAX_BATCH
-static __device__ __align__(256) float scratch[(size_t)NOALLOC_MAX_BATCH * PRED_GH];   // temb [batch][144]: 2.25 MiB per GPU
+static __device__ __align__(256) float scratch[(size_t)NOALLOC_MAX_BATCH * PRED_GH + PRED_MAXHS];   // temb [batch][144] | c0 [hs]: 2.25 MiB per GPU
 static float *g_scratch_ptr[64];
 static std::mutex g_scratch_mu;
 
@@ -780,9 +818,12 @@ extern "C" int dnag_pred_forward_grad_noalloc(const dnag_pred_dims *d, const flo
     const PredLayout lay = pred_layout(*d);
     const size_t nt = time_stride ? batch : 1;
     hipStream_t st = (hipStream_t)stream;
-    // every temb row the predictor kernel reads (nt rows) is rewritten by this launch: nothing of an earlier call survives
+    // every temb row the predictor kernel reads (nt rows) and all of c0 are rewritten by these launches: nothing of an
+    // earlier call survives
+    float *c0 = temb + (size_t)NOALLOC_MAX_BATCH * PRED_GH;
     if (int rc = launch_time_embed(time_cond, (int)nt, lay.g, packed, lay.freq, lay.t1_w, lay.t1_b, lay.t2_w, lay.t2_b, temb, st)) return rc;
-    return launch_predictor(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, d_mu, y, grad, batch, st);
+    if (int rc = launch_pred_c0(lay, packed, d_mu, c0, st)) return rc;
+    return launch_predictor(lay, packed, x, temb, time_stride ? 1 : 0, mask, mask_stride ? 1 : 0, c0, y, grad, batch, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -969,6 +1010,7 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
         if (int rc = predcate_prepare(pclay, p->predcate_packed, p->d_mu, ws + w.pc, pcw, st)) return rc;
     } else if (guided) {
         if (int rc = launch_time_embed(ws + w.labels, S, play.g, p->pred_packed, play.freq, play.t1_w, play.t1_b, play.t2_w, play.t2_b, ws + w.temb_p, st)) return rc;
+        if (int rc = launch_pred_c0(play, p->pred_packed, p->d_mu, ws + w.c0, st)) return rc;
     }
 
     float *x = ws + w.x, *x_mean = ws + w.x_mean, *cgrad = ws + w.cgrad, *gbuf = ws + w.gbuf, *partials = ws + w.partials;
@@ -988,7 +1030,7 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             if (guide_now) {
                 if (guided_pc) {
                     if (int rc = run_predcate(pclay, p->predcate_packed, x, ws + w.temb_p + (size_t)i * pclay.enc.d, 0, p->mask, 0, nullptr, cgrad, B, ws + w.pc, pcw, st)) return rc;
-                } else if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, p->d_mu, nullptr, cgrad, B, st)) return rc;
+                } else if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, ws + w.c0, nullptr, cgrad, B, st)) return rc;
                 float *rc_ = corr ? rec_at(p->rec_cgrad_c, ci) : rec_at(p->rec_cgrad_p, i);
                 if (rc_) HIP_TRY(hipMemcpyAsync(rc_, cgrad, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
             }

@@ -153,7 +153,7 @@ class MetaNeuralPredictor(DatasetBranch, PackedModule):
         d_mu = self._dataset_embedding(task, dev)
         dc = self.dims_c()
         packed = self.packed(dev)
-        ws = self._ws.get(max(B, 1) * self.dims.gcn_hidden * 4, dev)
+        ws = self._ws.get(lib.dnag_pred_workspace_bytes(C.byref(dc), max(B, 1)), dev)
         y = torch.empty(B, dtype=torch.float32, device=dev) if want_y else None
         g = torch.empty(B, N, V, dtype=torch.float32, device=dev) if want_grad else None
         with torch.cuda.device(dev):

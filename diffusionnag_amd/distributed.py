@@ -10,7 +10,9 @@ once per device would do.  ``sampler.langevin_batch = 'global'`` selects the exa
 (SURVEY.md 8e): one small all-gather of per-block norm sums per corrector update (``LangevinExchange``),
 after which every rank reduces the same list in the same order, so the step size is bit-identical to that
 of ONE batch holding all the graphs.  Philox noise is keyed by the global element index, so the noise a
-graph sees does not depend on the number of ranks.
+graph sees does not depend on the number of ranks.  Per-graph arithmetic is independent of the batch except for
+the power-of-two operand scales that the surrogate kernel derives per workgroup of 16 graphs: shard boundaries at
+multiples of 16 graphs (8192 per GPU in BASELINE configs[4]) keep every bit identical to the unsharded run.
 """
 
 from __future__ import annotations

@@ -115,6 +115,7 @@ int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, const float 
  * get_classifier_grad_fn (models/utils.py:126-147, regress=True): y [batch] (may be NULL) and
  * grad [batch][N][V] = d(sum_b y_b)/dx (may be NULL; caller applies the 'min' sign).
  * d_mu [nz] is the dataset embedding (digcn_meta.py:131-139) computed once per call. */
+size_t dnag_pred_workspace_bytes(const dnag_pred_dims *d, int batch);   /* batch = 1 when time_stride == 0 */
 int dnag_pred_forward_grad(const dnag_pred_dims *d, const float *packed, const float *x,
                            const float *time_cond, int time_stride, const float *mask, int mask_stride,
                            const float *d_mu, float *y, float *grad, int batch,

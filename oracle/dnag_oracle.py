@@ -365,7 +365,8 @@ def predictor_forward(sd: SD, X: Tensor, time_cond: Tensor, maskX: Tensor, D_mu:
     """MetaNeuralPredictor.forward with cached D_mu, digcn_meta.py:109-129, :141-159, :39-48."""
     B, N, _ = X.shape
     g = sd["fc1.weight"].shape[1]
-    emb_t = _lin(sd, "timeEmb2", F.silu(_lin(sd, "timeEmb1", timestep_embedding(time_cond, g))))  # :116-118
+    te = timestep_embedding(time_cond, g).to(sd["timeEmb1.weight"].dtype)     # fp32 in the reference; a no-op unless run in fp64
+    emb_t = _lin(sd, "timeEmb2", F.silu(_lin(sd, "timeEmb1", te)))              # :116-118
     adj = normalize_adj(maskX + torch.eye(N))                                   # :120
     out = X
     n_gcn = len([k for k in sd if k.startswith("gcn.") and k.endswith("weight1")])

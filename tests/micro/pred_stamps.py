@@ -16,7 +16,7 @@ task = synthetic.synthetic_task(10, 20, 2).to(dev)
 clf.sample_state = True; clf.D_mu = None
 for _ in range(5): g = clf.input_grad(X, t, m, task=task)
 torch.cuda.synchronize()
-st = g.reshape(-1)[5 * 8 * 8 * 7: 5 * 8 * 8 * 7 + 40].cpu().tolist()
+st = g.reshape(-1)[5 * 16 * 8 * 7: 5 * 16 * 8 * 7 + 64].cpu().tolist()      # block 5 = graphs 80..95 (16 per workgroup)
 prev = 0
 for i, v in enumerate(st):
     print(i, int(v), int(v - prev)); prev = v

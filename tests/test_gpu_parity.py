@@ -360,30 +360,52 @@ def whole_batch_cgrad(ours, grad_fn, B, rel, what, chunk=512, max_kinked=0.01):
     """Guidance gradient of every graph against the oracle's autograd.  Both surrogates are piecewise linear somewhere
     (ReLU: digcn_meta.py:43-45, transformer.py:106): a unit whose pre-activation is zero to rounding has no determined
     side in fp32, here or in the reference, and among ~10^7..10^8 units per batch a few dozen are.  A graph that misses
-    `rel` must match the oracle with such units counted as off or as on (relu threshold moved by 1e-6 of the layer's
-    largest pre-activation either way); such graphs must stay below `max_kinked` of the batch.
+    `rel` is examined on its own: its relu units with |pre-activation| below 5e-6 -- the path's parity tolerance -- of
+    the call's largest are the undecidable ones (e.g. -4.8e-8 against a maximum of 0.8: tests/micro/kink_diag.py), and
+    the graph must match the oracle to `rel` with SOME subset of at most three of them switched to the other side.
+    Such graphs must stay below `max_kinked` of the batch.
     grad_fn(slice) -> oracle gradient; it is called again under a patched oracle relu for the graphs that need it."""
+    import itertools
     from unittest import mock
     from oracle import dnag_oracle as O
     ours = ours.detach().cpu()
+    relu0 = O.F.relu
     kinked = 0
     for o in range(0, B, chunk):
         sl = slice(o, min(B, o + chunk))
         cg = grad_fn(sl)
         scale = float(cg.abs().max())
         e = (ours[sl] - cg).abs().flatten(1).max(dim=1).values
-        bad = e > rel * scale
-        if bad.any():
-            for side in (1e-6, -1e-6):
-                def relu(x, side=side):
-                    return x * (x > side * x.detach().abs().max()).to(x.dtype)
-                with mock.patch.object(O.F, "relu", relu):
-                    cg2 = grad_fn(sl)
-                e = torch.minimum(e, (ours[sl] - cg2).abs().flatten(1).max(dim=1).values)
-            still = e > rel * scale
-            assert not still.any(), (f"{what}: graphs {(torch.nonzero(still).flatten() + o).tolist()[:8]} differ from the oracle by "
-                                     f"{float(e.max()):.3e} > {rel:.1e} * {scale:.3e} on either side of a relu kink")
-            kinked += int(bad.sum())
+        for b in (torch.nonzero(e > rel * scale).flatten() + o).tolist():
+            one = slice(b, b + 1)
+            pre = []
+
+            def rec(v):
+                pre.append(v.detach().clone())
+                return relu0(v)
+            with mock.patch.object(O.F, "relu", rec):
+                grad_fn(one)
+            cands = [(k, int(i)) for k, v in enumerate(pre) for i in torch.nonzero(v.abs().flatten() < 5e-6 * v.abs().max()).flatten()]
+            assert 0 < len(cands) <= 12, f"{what}: graph {b} differs from the oracle by {float(e[b - o]):.3e} with {len(cands)} undecidable units"
+            best = float("inf")
+            for n in (1, 2, 3):
+                for sub in itertools.combinations(cands, n):
+                    calls = [0]
+
+                    def relu(v, sub=sub, calls=calls):
+                        on = (v > 0).flatten()
+                        for k, i in sub:
+                            if k == calls[0]:
+                                on[i] = ~on[i]
+                        calls[0] += 1
+                        return v * on.view(v.shape).to(v.dtype)
+                    with mock.patch.object(O.F, "relu", relu):
+                        best = min(best, float((ours[one] - grad_fn(one)).abs().max()))
+                if best <= rel * scale:
+                    break
+            assert best <= rel * scale, (f"{what}: graph {b} differs from the oracle by {best:.3e} > {rel:.1e} * {scale:.3e} whichever "
+                                         f"of its {len(cands)} undecidable relu units are switched")
+            kinked += 1
     assert kinked <= max_kinked * B, f"{what}: {kinked} of {B} graphs sit on a relu kink"
     return kinked
 

@@ -75,7 +75,8 @@ def test_gather_runs_through_rccl_on_a_one_rank_group():
 # ------------------------------------------------------------------------------------------------
 # exact-global-batch Langevin mode: two shards = the unsharded batch, bit for bit
 # ------------------------------------------------------------------------------------------------
-GB, GS = 48, 3          # graphs of the whole batch, PC steps
+GB, GS = 64, 3          # graphs of the whole batch, PC steps.  Shards of 32: a multiple of the 16 graphs a surrogate workgroup
+                        # shares its power-of-two operand scales over, so that a graph meets the same neighbours sharded or not
 
 
 def _guided_run(B, tape, offset, mode):
@@ -115,10 +116,10 @@ def _shard_worker(rank, world, port, path):
 
 
 def test_two_shards_reproduce_the_single_batch_step_size(tmp_path):
-    """Two processes (gloo between them, both on this GPU) sample the two halves of a 48-graph batch in the
+    """Two processes (gloo between them, both on this GPU) sample the two halves of a 64-graph batch in the
     exact-global-batch mode: every corrector update exchanges the per-block norm sums (dnag_pc_args.langevin_exchange)
     and reduces them in the order of the whole batch, so the step sizes -- and with them every state -- carry the same
-    bits as ONE process sampling all 48 graphs; in the default per-shard mode they differ."""
+    bits as ONE process sampling all 64 graphs; in the default per-shard mode they differ."""
     import socket
     import torch.multiprocessing as mp
     tape = synthetic.noise_tape(GS, (GB, 8, 7), 91)

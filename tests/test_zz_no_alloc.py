@@ -37,7 +37,7 @@ def test_noalloc_entry_point_matches_workspace_entry_point():
     st = _lib.current_stream(dev)
     for B, seed in ((200, 11), (37, 12)):       # the second call is smaller: stale rows of the first stay in the scratch
         X, t, m = _inputs(B, seed)
-        ws = torch.empty(B * d.gcn_hidden, dtype=torch.float32, device=DEV)
+        ws = torch.empty(lib.dnag_pred_workspace_bytes(C.byref(dc), B) // 4, dtype=torch.float32, device=DEV)
         y0, g0 = torch.empty(B, device=DEV), torch.empty(B, 8, 7, device=DEV)
         y1, g1 = torch.full((B,), float("nan"), device=DEV), torch.full((B, 8, 7), float("nan"), device=DEV)
         _lib.check(lib.dnag_pred_forward_grad(C.byref(dc), packed.data_ptr(), X.data_ptr(), t.data_ptr(), 1, m.data_ptr(), 1,
@@ -54,7 +54,7 @@ def test_noalloc_entry_point_matches_workspace_entry_point():
         assert torch.equal(g0, g1), f"B={B}: grad differs, max {float((g0 - g1).abs().max()):.3e}"
     # one shared time condition (time_stride 0), y only
     X, t, m = _inputs(64, 13)
-    ws = torch.empty(64 * d.gcn_hidden, dtype=torch.float32, device=DEV)
+    ws = torch.empty(lib.dnag_pred_workspace_bytes(C.byref(dc), 1) // 4, dtype=torch.float32, device=DEV)
     y0, y1 = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
     _lib.check(lib.dnag_pred_forward_grad(C.byref(dc), packed.data_ptr(), X.data_ptr(), t.data_ptr(), 0, m.data_ptr(), 0,
                                           d_mu.data_ptr(), y0.data_ptr(), None, 64, ws.data_ptr(), ws.numel() * 4, st), "ws")
