@@ -7,17 +7,22 @@
 // Here every activation that feeds a linear is normalised / scaled / split ONCE, by the phase that produces it, into an
 // LDS image of split-pair rows (dnag_gemm16.hip.h: per 8 values 16 B of fp16 hi, 16 B of lo), so a tile job is two
 // ds_read_b128 and three v_mfma_f32_32x32x16_f16 per 16 k:
-//   P0  row statistics of h: concat slice of the previous layer (output norm, transformer.py:177) and LN1(h) -> A16
+//   P0  finish the row statistics of h (see below): concat slice of the previous layer (output norm, transformer.py:177)
+//       and LN1(h) -> A16, from the wave's registers
 //   P1  q|k|v = A16 Wqkv'^T + b            (3 tile jobs per wave)                    -> qkv fp32 [64][192]
 //   P2  attention: one thread per (graph, head, query pair): K and V rows are read once for two queries and the
 //       two dot products / two output rows ride on packed fp32 FMAs                   -> A16 (scale sa_o)
-//   P3  h += A16 Wo^T + bo                 (the wave's tile of h lives in registers) -> hbuf
-//   P4  LN2(h) -> A16
+//   P3  h += A16 Wo^T + bo                 (the wave's tile of h lives in registers)
+//   P4  LN2(h) -> A16, from the wave's registers
 //   P5  hidden = relu(A16 W1'^T + b1'), MFMA operands swapped so that a lane owns one batch row and writes its 16
 //       columns as 4-value runs of the split image                                     -> hidden (scale sa_f2)
-//   P6  h += hidden W2^T + b2                                                         -> hbuf
-// The residual stream h is kept twice: in the accumulator layout in registers (one 32x32 tile per wave: P3 and P6 have
-// exactly four jobs), where the residual additions happen, and as fp32 rows in LDS for the row statistics.
+//   P6  h += hidden W2^T + b2
+// The residual stream h lives in registers only (round 2 also kept fp32 rows in LDS and re-read them for every
+// LayerNorm): one 32x32 tile per wave (P3 and P6 have exactly four jobs), computed with the MFMA operands swapped so that a
+// lane owns one batch row and 16 of the tile's 32 columns.  Row statistics: mean and centred sum of squares of the
+// lane's 16 values, merged with the other lane half (v_permlane32_swap) and -- through 8 bytes per row and tile in LDS,
+// across the barrier that separates the phases anyway -- with the wave that holds the row's other 32 columns (Chan's
+// pairwise update: no cancellation), then the wave normalises its own registers and writes its part of the split image.
 // Restates (reference NAS-Bench-201/): models/cate.py:145-160, models/transformer.py:12-20, :23-42, :69-80, :97-108,
 // :127-136, :166-179, models/cate.py:83-86.
 #pragma once
@@ -41,11 +46,11 @@ __device__ __forceinline__ v2f pk_max(v2f a, v2f b) { return v2f{fmaxf(a.x, b.x)
 
 struct Enc8Geom {
     static constexpr int N = 8, G = 8, R = 64, D = 64, H = 8, DK = 8, DFF = 128;
-    static constexpr int AS = D + 4;            // dword row stride of A16 and hbuf (== 4 mod 64: conflict-free ds_read_b128)
+    static constexpr int AS = D + 4;            // dword row stride of A16 (== 4 mod 64: conflict-free ds_read_b128)
     static constexpr int QS = 3 * D + 4;        // q|k|v rows
     static constexpr int FS = DFF + 4;          // split hidden rows (DFF values = DFF dwords)
-    static constexpr int BIG = R * FS + R * AS; // hidden, then hbuf behind it (qkv [R][QS] fits in front: R*QS <= BIG)
-    static_assert(R * QS <= BIG, "q|k|v aliases the hidden + hbuf region");
+    static constexpr int BIG = R * FS + R * AS; // hidden, then the embedding's staging rows / the row statistics (qkv [R][QS] aliases the front)
+    static_assert(R * QS + 4 * R <= BIG, "q|k|v aliases the hidden region; the row statistics [R][2][2] sit behind it");
     static constexpr int VEC = 3 * D + D + DFF + D;   // staged per layer: bqkv' | bo | b1' | b2, then two parity slots of on_g | on_b
     static constexpr size_t lds_floats = (size_t)R * AS + BIG + (size_t)G * N * N + VEC + 4 * D;
 };
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     float *big = a16 + R * AS;
     float *qkv = big;                        // [R][QS] fp32 (P1 -> P2)
     float *hid = big;                        // [R][FS] split-pair rows, 128 values each (P5 -> P6)
-    float *hbuf = big + R * FS;              // [R][AS] fp32 residual stream for the row statistics (P3 -> P4, P6 -> P0)
+    float *emb = big + 1024;                 // [R][AS] fp32 staging of the embedding (before layer 0 only; behind the staged x)
+    float *rst = big + R * QS;               // [R][2 column tiles][mean, M2]: 32-column row statistics, exchanged between the two waves of a row tile
     float *maskb = big + Ge::BIG;            // [G][N][N]
     float *bst = maskb + G * N * N;          // this layer's bias vectors: bqkv' [192] | bo [64] | b1' [128] | b2 [64]
     float *onst = bst + Ge::VEC;             // [2][on_g 64 | on_b 64]: output-norm affine of layer l in slot l & 1
@@ -143,16 +149,18 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 val = val + pe[n * D + c];
                 val = val + temb[(size_t)(tstride ? g0 + g : 0) * D + c];
             }
-            hbuf[rr * AS + c] = val;
+            emb[rr * AS + c] = val;
         }
     }
     __syncthreads();
+    // the wave's tile of h: lane = batch row tmt*32 + r, registers 4 gq + e = columns tnt*32 + 8 gq + 4 h + e
     f32x16 hacc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) hacc[i] = hbuf[(tmt * 32 + acc_row(i, h)) * AS + tnt * 32 + r];
+    for (int gq = 0; gq < 4; ++gq) {
+        const v4f v = *reinterpret_cast<const v4f *>(emb + (tmt * 32 + r) * AS + tnt * 32 + 8 * gq + 4 * h);
+        hacc[4 * gq + 0] = v.x; hacc[4 * gq + 1] = v.y; hacc[4 * gq + 2] = v.z; hacc[4 * gq + 3] = v.w;
+    }
 
-    // Row statistics of h (16 lanes per row, DPP sums): writes LN(h) * 16 as split-pair rows into A16 (to_a16) and
-    // the output norm of layer `lprev` as a concat slice (lprev >= 0).
     // The vectors of a layer (CateLayout::l_vec) are fetched one 16-byte piece per thread well ahead (stage_fetch: before
     // the loop, then behind P5 of the layer before) and parked in LDS at the start of P0 (stage_put), so no epilogue
     // waits for a global load that queues behind the weight prefetches.
@@ -167,54 +175,84 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             *reinterpret_cast<v4f *>(dst) = st4;
         }
     };
-    // Row statistics of h (16 lanes per row, DPP sums): writes LN(h) * 16 as split-pair rows into A16 (to_a16) and
-    // the output norm of layer `lprev` (lprev >= 0) as its concat slice.  (Holding the slice in registers to store it
-    // behind P1 -- whose wait for weight fragments also waits for these stores -- was measured: the 16 registers spill.)
-    auto norm_pass = [&](bool to_a16, int lprev) {
-        const int sub = tid & 15, slot = tid >> 4;
-        v4f g4 = {0.f, 0.f, 0.f, 0.f}, b4 = {0.f, 0.f, 0.f, 0.f};
-        if (lprev >= 0) {
-            g4 = *reinterpret_cast<const v4f *>(onst + (lprev & 1) * 2 * D + 4 * sub);
-            b4 = *reinterpret_cast<const v4f *>(onst + (lprev & 1) * 2 * D + D + 4 * sub);
-        }
+    // Row statistics of h, first half (behind the phase that produced hacc): mean and centred sum of squares of the
+    // lane's 16 values, merged with the other lane half (the tile's other 16 columns of the same row), parked in LDS for
+    // the wave that holds the row's other column tile.  own_m / own_q keep this tile's pair.
+    float own_m = 0.f, own_q = 0.f;
+    auto stats_put = [&]() {
+        float s_ = 0.f;
 #pragma unroll
-        for (int p = 0; p < R / 16; ++p) {
-            const int rr = slot + 16 * p;
-            v4f v = *reinterpret_cast<const v4f *>(hbuf + rr * AS + 4 * sub);
-            const float m = row16_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 64.0f);
-            v.x -= m; v.y -= m; v.z -= m; v.w -= m;
-            const float var = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w)) * (1.0f / 64.0f);
-            const float s = __builtin_amdgcn_rsqf(var + 1e-5f);     // v_rsq_f32: 1 ulp, the argument is a normal number
+        for (int i = 0; i < 16; ++i) s_ += hacc[i];
+        const float m16 = s_ * (1.0f / 16.0f);
+        float q16 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float d_ = hacc[i] - m16; q16 = fmaf(d_, d_, q16); }
+        // v_permlane32_swap with both operands = v: the first result carries lanes 0..31 of v in both halves, the second
+        // lanes 32..63
+        const auto pm = __builtin_amdgcn_permlane32_swap(__float_as_uint(m16), __float_as_uint(m16), false, false);
+        const auto pq = __builtin_amdgcn_permlane32_swap(__float_as_uint(q16), __float_as_uint(q16), false, false);
+        const float ma = __uint_as_float(pm[0]), mb = __uint_as_float(pm[1]);
+        const float dm = ma - mb;
+        own_m = (ma + mb) * 0.5f;
+        own_q = (__uint_as_float(pq[0]) + __uint_as_float(pq[1])) + dm * dm * 8.0f;        // n_a n_b / (n_a + n_b) = 8
+        if (h == 0) *reinterpret_cast<float2 *>(rst + ((tmt * 32 + r) * 2 + tnt) * 2) = float2{own_m, own_q};
+    };
+    // second half (behind the barrier): the other tile's pair -> mean and 1 / std of the 64-wide row
+    auto stats_get = [&](float &mean, float &rstd) {
+        const float2 o = *reinterpret_cast<const float2 *>(rst + ((tmt * 32 + r) * 2 + (tnt ^ 1)) * 2);
+        // merged in a fixed order (tile 0 first) so that both waves of a row derive the same bits
+        const float m0 = tnt ? o.x : own_m, m1 = tnt ? own_m : o.x, q0 = tnt ? o.y : own_q, q1 = tnt ? own_q : o.y;
+        const float dm = m0 - m1;
+        mean = (m0 + m1) * 0.5f;
+        const float var = ((q0 + q1) + dm * dm * 16.0f) * (1.0f / 64.0f);
+        rstd = __builtin_amdgcn_rsqf(var + 1e-5f);     // v_rsq_f32: 1 ulp, the argument is a normal number
+    };
+    // LN(h) * 16 of the wave's registers as split-pair quads into A16 (to_a16), and the output norm of layer `lprev`
+    // (lprev >= 0) as its concat slice
+    auto norm_write = [&](bool to_a16, int lprev) {
+        float mean, rstd;
+        stats_get(mean, rstd);
+        const int row = tmt * 32 + r;
+        const bool live = g0 + row / N < batch;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int c0 = tnt * 32 + 8 * gq + 4 * h;                 // first of the quad's columns
+            const int at = (c0 >> 3) * 16 + (c0 & 7);                  // its place in a split-pair row, in halves (lo: + 8)
+            v4f u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = (hacc[4 * gq + e] - mean) * rstd;
             if (to_a16) {
-                // value k = 4 sub + e of the row sits at half (k >> 3) * 16 + (k & 7) of its split-pair row (lo: + 8)
-                const int at = (sub >> 1) * 16 + (sub & 1) * 4;
                 h4 hi, lo;
-                split4(v4f{v.x * s * 16.0f, v.y * s * 16.0f, v.z * s * 16.0f, v.w * s * 16.0f}, hi, lo);
-                _Float16 *dst = reinterpret_cast<_Float16 *>(a16 + rr * AS) + at;
+                split4(u * 16.0f, hi, lo);
+                _Float16 *dst = reinterpret_cast<_Float16 *>(a16 + row * AS) + at;
                 *reinterpret_cast<h4 *>(dst) = hi;
                 *reinterpret_cast<h4 *>(dst + 8) = lo;
             }
             if (lprev >= 0) {
+                const v4f g4 = *reinterpret_cast<const v4f *>(onst + (lprev & 1) * 2 * D + c0);
+                const v4f b4 = *reinterpret_cast<const v4f *>(onst + (lprev & 1) * 2 * D + D + c0);
                 v4f o4;
-                o4.x = v.x * s * g4.x + b4.x; o4.y = v.y * s * g4.y + b4.y;
-                o4.z = v.z * s * g4.z + b4.z; o4.w = v.w * s * g4.w + b4.w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o4[e] = u[e] * g4[e] + b4[e];
                 h4 hi, lo;
                 split4(o4 * sa_concat, hi, lo);
-                if (g0 + rr / N < batch) {
-                    const int at = (sub >> 1) * 16 + (sub & 1) * 4;
-                    _Float16 *dst = reinterpret_cast<_Float16 *>(concat) + kblock_half_at((size_t)g0 * N + rr, lprev * (2 * D) + at, rows_pad);
+                if (live) {
+                    _Float16 *dst = reinterpret_cast<_Float16 *>(concat) + kblock_half_at((size_t)g0 * N + row, lprev * (2 * D) + at, rows_pad);
                     *reinterpret_cast<h4 *>(dst) = hi;
                     *reinterpret_cast<h4 *>(dst + 8) = lo;
                 }
             }
         }
     };
+    stats_put();
     stage_fetch(0);
     E8_STAMP();
     for (int l = 0; l <= L; ++l) {
         // ---- P0: statistics of h -> concat slice l - 1, A16 = LN1(h) -----------------------------------
+        __syncthreads();                     // the statistics of both column tiles are in LDS; every reader of A16 / bst is done
+        E8_STAMP();
         if (l < L) stage_put(l);
-        norm_pass(l < L, l - 1);
+        norm_write(l < L, l - 1);
         if (l == L) break;
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
         const float *LP16 = P16 + lay.layer0 + (size_t)l * lay.layer_stride;
@@ -350,23 +388,23 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 const int o = 8 * s;
                 const h8 bhi = __builtin_bit_cast(h8, v4f{bP[o], bP[o + 1], bP[o + 2], bP[o + 3]});
                 const h8 blo = __builtin_bit_cast(h8, v4f{bP[o + 4], bP[o + 5], bP[o + 6], bP[o + 7]});
-                acc = mfma16(ahi, bhi, acc);
-                acc = mfma16(ahi, blo, acc);
-                acc = mfma16(alo, bhi, acc);
+                acc = mfma16(bhi, ahi, acc);      // D[n][m]: lane = batch row m, registers = columns n (as in P5)
+                acc = mfma16(blo, ahi, acc);
+                acc = mfma16(bhi, alo, acc);
             }
-            const int col = tnt * 32 + r;
-            const float bv = bst[3 * D + col];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                hacc[i] = (acc[i] * inv + bv) + hacc[i];
-                hbuf[(tmt * 32 + acc_row(i, h)) * AS + col] = hacc[i];
+            for (int gq = 0; gq < 4; ++gq) {
+                const v4f b4 = *reinterpret_cast<const v4f *>(bst + 3 * D + tnt * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hacc[4 * gq + e] = (acc[4 * gq + e] * inv + b4[e]) + hacc[4 * gq + e];
             }
+            stats_put();
         }
         if (l + 1 < L) fetch64(LP16 + lay.layer_stride + lay.l_wqkv, q0, bP);      // next layer's P1
         __syncthreads();
         E8_STAMP();
-        // ---- P4: A16 = LN2(h) -----------------------------------------------------------------------------
-        norm_pass(true, -1);
+        // ---- P4: A16 = LN2(h), from the registers ------------------------------------------------------------
+        norm_write(true, -1);
         __syncthreads();
         E8_STAMP();
         // ---- P5: hidden = relu(LN2(h) W1'^T + b1'), transposed tiles: lane <-> batch row ---------------------
@@ -428,20 +466,18 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 const int o = 8 * s;
                 const h8 bhi = __builtin_bit_cast(h8, v4f{bR[o], bR[o + 1], bR[o + 2], bR[o + 3]});
                 const h8 blo = __builtin_bit_cast(h8, v4f{bR[o + 4], bR[o + 5], bR[o + 6], bR[o + 7]});
-                acc = mfma16(ahi, bhi, acc);
-                acc = mfma16(ahi, blo, acc);
-                acc = mfma16(alo, bhi, acc);
+                acc = mfma16(bhi, ahi, acc);
+                acc = mfma16(blo, ahi, acc);
+                acc = mfma16(bhi, alo, acc);
             }
-            const int col = tnt * 32 + r;
-            const float bv = bst[4 * D + DFF + col];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                hacc[i] = (acc[i] * inv + bv) + hacc[i];
-                hbuf[(tmt * 32 + acc_row(i, h)) * AS + col] = hacc[i];
+            for (int gq = 0; gq < 4; ++gq) {
+                const v4f b4 = *reinterpret_cast<const v4f *>(bst + 4 * D + DFF + tnt * 32 + 8 * gq + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hacc[4 * gq + e] = (acc[4 * gq + e] * inv + b4[e]) + hacc[4 * gq + e];
             }
+            stats_put();
         }
-        __syncthreads();
-        E8_STAMP();
     }
 #ifdef ENC8_STAMPS
     if (blockIdx.x == 5 && tid == 0) for (int i = 1; i < nts_; ++i) printf("e8 %d %lld\n", i, ts_[i] - ts_[i - 1]);
