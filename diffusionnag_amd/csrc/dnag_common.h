@@ -32,7 +32,10 @@ struct CateLayout {
                                   // what encoder8_kernel stages into LDS with one 16-byte load per thread
     size_t f0_w, f0_b, f1_w, f1_b, f2_w, f2_b;  // final.linears.{0,1,2}
     size_t pe, freq;              // [N][d], [d/2]
-    size_t f0_s, f1_s;            // final.linears.{0,1} weights as split-pair fp16 rows (dnag_gemm16.hip.h), same sizes
+    size_t f0_s, f1_s;            // final.linears.{0,1} weights as split-pair fp16 rows (dnag_gemm16.hip.h), same sizes.  f0_s holds
+                                  // W0 diag(gamma) with the affine of the per-layer output norms (encoder_f.norms.l) folded in: the
+                                  // encoders write the concat WITHOUT that affine (LN(h) * 16, the very rows the next layer's QKV reads)
+    size_t f0_bs;                 // [Hd] b0 + W0 beta: the bias that goes with f0_s
     size_t hsc;                   // 16 power-of-two scale factors of the head GEMMs (HEAD_SC_*)
     size_t delta16;               // layer0 + delta16: second copy of the layer blocks whose four matrices are fp16 hi/lo
                                   // fragments scaled by 256 (frag16_pack) for the encoder's split-arithmetic MFMAs
@@ -79,6 +82,7 @@ static inline __host__ __device__ CateLayout cate_layout(const dnag_cate_dims &c
     y.freq = o; o += align4(d / 2);
     y.f0_s = o; o += Hd * F;
     y.f1_s = o; o += Hd * Hd;
+    y.f0_bs = o; o += Hd;
     y.hsc = o; o += 16;
     y.delta16 = o - y.layer0; o += y.layer_stride * y.L;
     y.total = o;
@@ -134,7 +138,7 @@ static inline __host__ __device__ float act_scale(float bound) { return split_po
 #define ENC_SC_SA_F2   4   // scale of the FFN hidden
 #define ENC_SC_INV_F2  5   // 1 / (sa_f2 sw_2)
 // head table at hsc
-#define HEAD_SC_SA_CONCAT 0   // scale of the concat rows the encoder writes
+#define HEAD_SC_SA_CONCAT 0   // scale of the concat rows the encoders write: 16, the scale of every LayerNorm image (|LN(h)| < 8)
 #define HEAD_SC_F0        4   // final.linears.0: [0] 1 / (sa_in sw), [1] sa_out (the hidden it writes), [2], [3] unused
 #define HEAD_SC_F1        8   // final.linears.1 + .2 fused: [0] 1 / (sa_in sw), [1] sa of the ELU output, [2] sw of W3, [3] 1 / ([1] [2])
 

@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         h4_t hi4, lo4;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float sv16 = o4[e] * sa_concat;
+                            const float sv16 = v[e] * s * sa_concat;      // LN(h) without the affine (folded into final.linears.0, CateLayout::f0_s)
                             const _Float16 hi = (_Float16)sv16;
                             hi4[e] = hi;
                             lo4[e] = (_Float16)(sv16 - (float)hi);

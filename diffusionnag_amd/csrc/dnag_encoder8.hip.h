@@ -51,8 +51,8 @@ struct Enc8Geom {
     static constexpr int FS = DFF + 4;          // split hidden rows (DFF values = DFF dwords)
     static constexpr int BIG = R * FS + R * AS; // hidden, then the embedding's staging rows / the row statistics (qkv [R][QS] aliases the front)
     static_assert(R * QS + 4 * R <= BIG, "q|k|v aliases the hidden region; the row statistics [R][2][2] sit behind it");
-    static constexpr int VEC = 3 * D + D + DFF + D;   // staged per layer: bqkv' | bo | b1' | b2, then two parity slots of on_g | on_b
-    static constexpr size_t lds_floats = (size_t)R * AS + BIG + (size_t)G * N * N + VEC + 4 * D;
+    static constexpr int VEC = 3 * D + D + DFF + D;   // staged per layer: bqkv' | bo | b1' | b2
+    static constexpr size_t lds_floats = (size_t)R * AS + BIG + (size_t)G * N * N + VEC;
 };
 
 // hi/lo halves of four values that already carry their power-of-two scale
@@ -82,14 +82,12 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     float *rst = big + R * QS;               // [R][2 column tiles][mean, M2]: 32-column row statistics, exchanged between the two waves of a row tile
     float *maskb = big + Ge::BIG;            // [G][N][N]
     float *bst = maskb + G * N * N;          // this layer's bias vectors: bqkv' [192] | bo [64] | b1' [128] | b2 [64]
-    float *onst = bst + Ge::VEC;             // [2][on_g 64 | on_b 64]: output-norm affine of layer l in slot l & 1
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
-    const float sa_concat = P[lay.hsc + HEAD_SC_SA_CONCAT];
     const size_t rows_pad = ((size_t)batch * N + 255) / 256 * 256;      // the concat is k-tile blocked (dnag_gemm16.hip.h kblock_at)
     const float *P16 = P + lay.delta16;      // fp16 hi/lo fragment copy of the layer matrices
 
@@ -164,16 +162,14 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     // The vectors of a layer (CateLayout::l_vec) are fetched one 16-byte piece per thread well ahead (stage_fetch: before
     // the loop, then behind P5 of the layer before) and parked in LDS at the start of P0 (stage_put), so no epilogue
     // waits for a global load that queues behind the weight prefetches.
-    constexpr int NST = (Ge::VEC + 2 * D) / 4;
+    constexpr int NST = Ge::VEC / 4;
     v4f st4 = {0.f, 0.f, 0.f, 0.f};
     auto stage_fetch = [&](int lstage) {
         if (tid < NST) st4 = *reinterpret_cast<const v4f *>(P + lay.layer0 + (size_t)lstage * lay.layer_stride + lay.l_vec + 4 * tid);
     };
     auto stage_put = [&](int lstage) {
-        if (tid < NST) {
-            float *dst = tid < Ge::VEC / 4 ? bst + 4 * tid : onst + (lstage & 1) * 2 * D + (4 * tid - Ge::VEC);
-            *reinterpret_cast<v4f *>(dst) = st4;
-        }
+        (void)lstage;
+        if (tid < NST) *reinterpret_cast<v4f *>(bst + 4 * tid) = st4;
     };
     // Row statistics of h, first half (behind the phase that produced hacc): mean and centred sum of squares of the
     // lane's 16 values, merged with the other lane half (the tile's other 16 columns of the same row), parked in LDS for
@@ -207,13 +203,14 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         const float var = ((q0 + q1) + dm * dm * 16.0f) * (1.0f / 64.0f);
         rstd = __builtin_amdgcn_rsqf(var + 1e-5f);     // v_rsq_f32: 1 ulp, the argument is a normal number
     };
-    // LN(h) * 16 of the wave's registers as split-pair quads into A16 (to_a16), and the output norm of layer `lprev`
-    // (lprev >= 0) as its concat slice
-    auto norm_write = [&](bool to_a16, int lprev) {
+    // LN(h) * 16 of the wave's registers as split-pair quads into A16.  These rows are both the next layer's QKV operand
+    // and -- the affine of the output norm being folded into final.linears.0 (CateLayout::f0_s) -- the concat slice of
+    // the layer that just ended, which concat_out copies to HBM.
+    auto norm_write = [&]() {
         float mean, rstd;
         stats_get(mean, rstd);
         const int row = tmt * 32 + r;
-        const bool live = g0 + row / N < batch;
+        rstd *= 16.0f;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int c0 = tnt * 32 + 8 * gq + 4 * h;                 // first of the quad's columns
@@ -221,26 +218,23 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             v4f u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) u[e] = (hacc[4 * gq + e] - mean) * rstd;
-            if (to_a16) {
-                h4 hi, lo;
-                split4(u * 16.0f, hi, lo);
-                _Float16 *dst = reinterpret_cast<_Float16 *>(a16 + row * AS) + at;
-                *reinterpret_cast<h4 *>(dst) = hi;
-                *reinterpret_cast<h4 *>(dst + 8) = lo;
-            }
-            if (lprev >= 0) {
-                const v4f g4 = *reinterpret_cast<const v4f *>(onst + (lprev & 1) * 2 * D + c0);
-                const v4f b4 = *reinterpret_cast<const v4f *>(onst + (lprev & 1) * 2 * D + D + c0);
-                v4f o4;
+            h4 hi, lo;
+            split4(u, hi, lo);
+            _Float16 *dst = reinterpret_cast<_Float16 *>(a16 + row * AS) + at;
+            *reinterpret_cast<h4 *>(dst) = hi;
+            *reinterpret_cast<h4 *>(dst + 8) = lo;
+        }
+    };
+    // concat slice `lc` = the A16 image, copied out with full 128-byte lines: 64 rows x 2 chunks x 8 pieces of 16 bytes,
+    // four pieces per thread (k-tile-blocked rows: dnag_gemm16.hip.h kblock_at).  Runs between the barrier behind P0 and
+    // the one behind P1 (P2 is the next writer of A16).
+    auto concat_out = [&](int lc) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] = u[e] * g4[e] + b4[e];
-                h4 hi, lo;
-                split4(o4 * sa_concat, hi, lo);
-                if (live) {
-                    _Float16 *dst = reinterpret_cast<_Float16 *>(concat) + kblock_half_at((size_t)g0 * N + row, lprev * (2 * D) + at, rows_pad);
-                    *reinterpret_cast<h4 *>(dst) = hi;
-                    *reinterpret_cast<h4 *>(dst + 8) = lo;
-                }
+        for (int k = 0; k < 4; ++k) {
+            const int pc = tid + 256 * k, row = pc >> 4, dw = (pc & 15) * 4;
+            if (g0 + row / N < batch) {
+                const v4f v = *reinterpret_cast<const v4f *>(a16 + row * AS + dw);
+                *reinterpret_cast<v4f *>(concat + kblock_at((size_t)g0 * N + row, (size_t)lc * D + dw, rows_pad)) = v;
             }
         }
     };
@@ -252,14 +246,19 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         __syncthreads();                     // the statistics of both column tiles are in LDS; every reader of A16 / bst is done
         E8_STAMP();
         if (l < L) stage_put(l);
-        norm_write(l < L, l - 1);
-        if (l == L) break;
+        norm_write();
+        if (l == L) {
+            __syncthreads();
+            concat_out(L - 1);
+            break;
+        }
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
         const float *LP16 = P16 + lay.layer0 + (size_t)l * lay.layer_stride;
         const float *SC = LP + lay.l_sc;
         __syncthreads();
         E8_STAMP();
-        // ---- P1: q|k|v -------------------------------------------------------------------------------
+        // ---- P1: q|k|v (and the concat slice of the layer before: the rows P1 reads) -----------------------
+        if (l > 0) concat_out(l - 1);
         {
             const float inv = SC[ENC_SC_INV_QKV];
             const float *bias = bst;
@@ -404,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         __syncthreads();
         E8_STAMP();
         // ---- P4: A16 = LN2(h), from the registers ------------------------------------------------------------
-        norm_write(true, -1);
+        norm_write();
         __syncthreads();
         E8_STAMP();
         // ---- P5: hidden = relu(LN2(h) W1'^T + b1'), transposed tiles: lane <-> batch row ---------------------

@@ -67,6 +67,21 @@ __global__ void unsplit_kernel(const float *__restrict__ in, float *__restrict__
     }
 }
 
+// The concat the encoders write (LN(h) * 16 per layer slice, k-tile-blocked split-pair rows) -> the reference's concat
+// (cate.py:83-86): o_l = LN(h) gamma_l + beta_l, fp32 [rows][L * d].  For tests and the concat_out of dnag_cate_forward.
+__global__ void unsplit_concat_kernel(const float *__restrict__ in, float *__restrict__ out, size_t rows, size_t rows_pad,
+                                      const float *__restrict__ P, const CateLayout lay) {
+    const _Float16 *p = reinterpret_cast<const _Float16 *>(in);
+    const size_t K = (size_t)lay.F, n = rows * K;
+    const float sa = P[lay.hsc + HEAD_SC_SA_CONCAT];
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e / K, k = e - r * K, l = k / lay.d, c = k - l * lay.d;
+        const size_t at = kblock_half_at(r, split_at(k), rows_pad);
+        const float *LP = P + lay.layer0 + l * lay.layer_stride;
+        out[e] = ((float)p[at] + (float)p[at + 8]) / sa * LP[lay.l_ong + c] + LP[lay.l_onb + c];
+    }
+}
+
 // C = act(A W^T + bias) with A [M][K] (scale SPLIT_SA) and W [Nout][K] (scale SPLIT_SW) in split-pair rows,
 // row pitch K floats.  OUT_SPLIT: C is written as split-pair activation rows (the next GEMM's A operand), else
 // plain fp32 [M][Nout].

@@ -192,10 +192,8 @@ static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *
         SC[ENC_SC_SA_F2] = sa_f2;
         SC[ENC_SC_INV_F2] = 1.0f / (sa_f2 * sw_2);
     }
-    float cbound = 0.f;               // |concat| <= 8 max|gamma| + max|beta| over the output norms
     for (size_t l = 0; l < L; ++l) {   // encoder_f.norms.l
         float *LP = out + y.layer0 + l * y.layer_stride;
-        cbound = fmaxf(cbound, sqrtf((float)d) * amax_of(s + o, d) + amax_of(s + o + d, d));
         memcpy(LP + y.l_ong, s + o, d * sizeof(float)); o += d;
         memcpy(LP + y.l_onb, s + o, d * sizeof(float)); o += d;
         float *vec = LP + y.l_vec;     // contiguous copy of the layer's vectors
@@ -210,18 +208,34 @@ static int cate_pack_impl(const dnag_cate_dims &c, const float *s, const float *
     take(y.f1_w, Hd * Hd); take(y.f1_b, Hd);
     take(y.f2_w, V * Hd); take(y.f2_b, V);
     {
+        // final.linears.0 on the concat of the per-layer output norms: o_l = LN(h) gamma_l + beta_l.  The affine is folded
+        // into the split copy (W0' = W0 diag(gamma), b0' = b0 + W0 beta), so the encoders write LN(h) itself.
+        std::vector<float> w0f(Hd * F);
+        for (size_t j = 0; j < Hd; ++j) {
+            double acc = out[y.f0_b + j];
+            for (size_t l = 0; l < L; ++l) {
+                const float *og = out + y.layer0 + l * y.layer_stride + y.l_ong, *ob = out + y.layer0 + l * y.layer_stride + y.l_onb;
+                for (size_t k = 0; k < d; ++k) {
+                    const float w = out[y.f0_w + j * F + l * d + k];
+                    w0f[j * F + l * d + k] = w * og[k];
+                    acc += (double)w * (double)ob[k];
+                }
+            }
+            out[y.f0_bs + j] = (float)acc;
+        }
         float *H = out + y.hsc;
-        const float sa_c = act_scale(cbound);
-        const float sw0 = weight_scale(amax_of(out + y.f0_w, Hd * F)), sw1 = weight_scale(amax_of(out + y.f1_w, Hd * Hd));
+        const float cbound = sqrtf((float)d);          // |LN(h)| < sqrt(d) = 8
+        const float sa_c = 16.0f;                       // the scale of every LayerNorm image (act_scale(8) = 16 as well)
+        const float sw0 = weight_scale(amax_of(w0f.data(), Hd * F)), sw1 = weight_scale(amax_of(out + y.f1_w, Hd * Hd));
         const float sw3 = weight_scale(amax_of(out + y.f2_w, V * Hd));
         // |elu(z)| <= max(|z|, 1)
-        const float h1b = fmaxf(1.0f, bound_l1_linear(out + y.f0_w, out + y.f0_b, Hd, F, cbound));
+        const float h1b = fmaxf(1.0f, bound_l1_linear(w0f.data(), out + y.f0_bs, Hd, F, cbound));
         const float h2b = fmaxf(1.0f, bound_l1_linear(out + y.f1_w, out + y.f1_b, Hd, Hd, h1b));
         const float sa1 = act_scale(h1b), sa2 = act_scale(h2b);
         H[HEAD_SC_SA_CONCAT] = sa_c;
         H[HEAD_SC_F0 + 0] = 1.0f / (sa_c * sw0); H[HEAD_SC_F0 + 1] = sa1;
         H[HEAD_SC_F1 + 0] = 1.0f / (sa1 * sw1); H[HEAD_SC_F1 + 1] = sa2; H[HEAD_SC_F1 + 2] = sw3; H[HEAD_SC_F1 + 3] = 1.0f / (sa2 * sw3);
-        split_pack(out + y.f0_w, Hd, F, out + y.f0_s, sw0);
+        split_pack(w0f.data(), Hd, F, out + y.f0_s, sw0);
         split_pack(out + y.f1_w, Hd, Hd, out + y.f1_s, sw1);
         kblock_rows(out + y.f0_s, Hd, F);
         kblock_rows(out + y.f1_s, Hd, Hd);
@@ -722,7 +736,7 @@ static int run_score_body(const dnag_cate_dims &c, const CateLayout &lay, const 
                           int tstride, const float *mask, int mstride, float *ws, const WsLayout &w, float *attn0, int batch,
                           hipStream_t st) {
     if (int rc = launch_encoder(c, lay, P, x, temb, tstride, mask, mstride, ws + w.concat, attn0, batch, st)) return rc;
-    if (int rc = launch_gemm(ws + w.concat, P + lay.f0_s, P + lay.f0_b, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st, P + lay.hsc + HEAD_SC_F0)) return rc;
+    if (int rc = launch_gemm(ws + w.concat, P + lay.f0_s, P + lay.f0_bs, ws + w.h1, w.rows_pad, lay.Hd, lay.F, false, w.rows, st, P + lay.hsc + HEAD_SC_F0)) return rc;
     // final.linears.1 with final.linears.2 fused into its epilogue: ws.h2 receives [Hd / 256][rows_pad][V] partial sums
     if (int rc = launch_gemm(ws + w.h1, P + lay.f1_s, P + lay.f1_b, ws + w.h2, w.rows_pad, lay.Hd, lay.Hd, true, w.rows, st, P + lay.hsc + HEAD_SC_F1, P + lay.f2_w, lay.V)) return rc;
     return 0;
@@ -749,7 +763,7 @@ extern "C" int dnag_cate_forward(const dnag_cate_dims *d, const float *packed, c
     a.parts = ws + w.h2; a.nparts = lay.Hd / SplitGeom::BN; a.part_stride = w.rows_pad * (size_t)lay.V;
     if (int rc = launch_exit(*d, lay, packed, ws + w.h2, a, st)) return rc;
     if (concat_out) {   // the workspace holds split-pair rows; hand back plain fp32
-        hipLaunchKernelGGL(unsplit_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, w.rows_pad, lay.F, packed + lay.hsc + HEAD_SC_SA_CONCAT);
+        hipLaunchKernelGGL(unsplit_concat_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, concat_out, w.rows, w.rows_pad, packed, lay);
         LAUNCH_CHECK();
     }
     return 0;

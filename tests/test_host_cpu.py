@@ -106,7 +106,7 @@ def test_cate_pack_folds_layernorm_into_linear():
     f0 = layer0 + 12 * stride
     assert np.array_equal(packed[f0: f0 + 1536 * 768].astype(np.float32), sd["final.linears.0.weight"].numpy().ravel())
     # derived tables = the oracle's restatement of the reference constructors
-    n_split = 1536 * 768 + 1536 * 1536                 # split-pair copies of final.linears.{0,1} ...
+    n_split = 1536 * 768 + 1536 * 1536 + 1536          # split-pair copies of final.linears.{0,1} and the folded bias of .0 ...
     n_l16 = 12 * stride                                # ... and the fp16-fragment copy of the layer blocks close the blob
     n_hsc = 16                                         # head GEMM operand scales, between the two
     tail = packed[-(8 * 64 + 32) - n_split - n_hsc - n_l16: -n_split - n_hsc - n_l16]
@@ -126,7 +126,16 @@ def test_cate_pack_folds_layernorm_into_linear():
     # ... stored k-tile blocked (kblock_rows): [k tile of 32][row][32 dwords]
     rows_major = raw[: 1536 * 768].reshape(768 // 32, 1536, 32).transpose(1, 0, 2).reshape(-1).copy()
     halves = rows_major.view(np.float16).reshape(1536, 768 // 8, 2, 8).astype(np.float64)
-    w0 = sd["final.linears.0.weight"].double().numpy()
+    # final.linears.0 carries the affine of the per-layer output norms (the encoders write LN(h) itself as the concat):
+    # W0' = W0 diag(gamma), b0' = b0 + W0 beta  (transformer.py:177, cate.py:83-86, :55-73)
+    gam = np.concatenate([sd[f"graph_encoder.encoder_f.norms.{l}.weight"].double().numpy() for l in range(12)])
+    bet = np.concatenate([sd[f"graph_encoder.encoder_f.norms.{l}.bias"].double().numpy() for l in range(12)])
+    w0_plain = sd["final.linears.0.weight"].double().numpy()
+    w0 = (sd["final.linears.0.weight"].numpy() * gam.astype(np.float32)[None, :]).astype(np.float64)
+    b0f = raw[1536 * 768 + 1536 * 1536:].astype(np.float64)
+    assert np.abs(b0f - (sd["final.linears.0.bias"].double().numpy() + w0_plain @ bet)).max() < 1e-6
+    hrow = rs.standard_normal((3, 768))
+    assert np.abs((hrow * gam + bet) @ w0_plain.T + sd["final.linears.0.bias"].double().numpy() - (hrow @ w0.T + b0f)).max() < 1e-5
     rec = (halves[:, :, 0, :] + halves[:, :, 1, :]).reshape(1536, 768) / 256.0
     assert np.abs(rec - w0).max() <= 2.0 ** -21 * np.abs(w0).max()
     assert np.array_equal(halves[:, :, 0, :].reshape(1536, 768), (w0 * 256).astype(np.float16).astype(np.float64))
@@ -153,29 +162,35 @@ def test_cate_pack_scales_follow_large_weights():
     sd = synthetic.cate_state_dict(dims, seed=0)
     sd["final.linears.1.weight"][5, 7] = 300.0                                          # 256 * 300 > 65504
     sd["graph_encoder.encoder_f.layers.2.feed_forward.feed_forward.w_1.weight"] *= 4000.0   # FFN hidden beyond 4094
-    sd["graph_encoder.encoder_f.norms.4.weight"] *= 900.0                               # |concat| up to 7200
+    sd["graph_encoder.encoder_f.norms.4.weight"] *= 900.0                               # folded into final.linears.0: W0 diag(gamma)
     model.load_state_dict(sd)
     raw = model._pack_host(model._state_flat().contiguous()).numpy()
     d, V, dff = 64, 7, 128
     layer0 = d * V + d + 4 * d * d + 4 * d + 4 * d * d + d
     stride = 3 * d * d + 3 * d + d * d + d + dff * d + dff + d * dff + d + 2 * d + 8 + (7 * d + dff)
-    n_split, n_l16 = 1536 * 768 + 1536 * 1536, 12 * stride
+    n_l16 = 12 * stride
     hsc = raw[-16 - n_l16: -n_l16].astype(np.float64)
     sa_c, sa1, sa2, sw3 = hsc[0], hsc[5], hsc[9], hsc[10]
     sw0, sw1 = 1 / (hsc[4] * sa_c), 1 / (hsc[8] * sa1)
     for v in (sa_c, sa1, sa2, sw0, sw1, sw3):
         assert v > 0 and np.log2(v) == int(np.log2(v))                                   # powers of two
-    assert sw0 == 256 and sw3 == 256 and sw1 == 128 and sw1 * 300 <= 60000 < 2 * sw1 * 300
-    cbound = 8 * 900.0                                                                   # 8 max|gamma| + max|beta|
-    assert sa_c * cbound <= 60000 < 2 * sa_c * cbound and sa_c == 8
-    w0 = sd["final.linears.0.weight"].double().numpy()
-    h1b = max(1.0, (np.abs(w0).sum(1) * cbound + np.abs(sd["final.linears.0.bias"].double().numpy())).max())
+    assert sw3 == 256 and sw1 == 128 and sw1 * 300 <= 60000 < 2 * sw1 * 300
+    cbound = 8.0                                                                         # the concat is LN(h) itself: |LN(h)| < 8
+    assert sa_c == 16
+    gam = np.concatenate([sd[f"graph_encoder.encoder_f.norms.{l}.weight"].double().numpy() for l in range(12)])
+    bet = np.concatenate([sd[f"graph_encoder.encoder_f.norms.{l}.bias"].double().numpy() for l in range(12)])
+    w0_plain = sd["final.linears.0.weight"].double().numpy()
+    w0 = w0_plain * gam[None, :]
+    b0f = sd["final.linears.0.bias"].double().numpy() + w0_plain @ bet
+    assert sw0 * np.abs(w0).max() <= 60000 < 2 * sw0 * np.abs(w0).max() or sw0 == 256
+    h1b = max(1.0, (np.abs(w0).sum(1) * cbound + np.abs(b0f)).max())
     assert sa1 * h1b <= 60000 * 1.001 and (sa1 == 16 or 2 * sa1 * h1b > 60000)
     w1 = sd["final.linears.1.weight"].double().numpy()
     h2b = max(1.0, (np.abs(w1).sum(1) * h1b + np.abs(sd["final.linears.1.bias"].double().numpy())).max())
     assert sa2 * h2b <= 60000 * 1.001 and (sa2 == 16 or 2 * sa2 * h2b > 60000)
     # the split-pair copy of final.linears.1 carries sw1 and reproduces the weights to 22 bits, 300 included
-    f1s = raw[-n_split - 16 - n_l16 + 1536 * 768: -16 - n_l16]
+    n_split = 1536 * 768 + 1536 * 1536 + 1536                                          # f0_s | f1_s | folded bias of final.linears.0
+    f1s = raw[-n_split - 16 - n_l16 + 1536 * 768: -16 - n_l16 - 1536]
     f1s = f1s.reshape(1536 // 32, 1536, 32).transpose(1, 0, 2).reshape(-1).copy()       # k-tile blocked -> rows
     halves = f1s.view(np.float16).reshape(1536, 1536 // 8, 2, 8).astype(np.float64)
     assert np.isfinite(halves).all()
@@ -244,7 +259,7 @@ def test_predictor_cate_pack_layout():
     assert np.array_equal(packed[f0: f0 + Hd * F], sdp["final.linears.0.weight"].numpy().ravel())
     tab_end = f0 + Hd * F + Hd + Hd * Hd + Hd + al4(V * Hd) + al4(V) + al4(20 * D_) + al4(D_ // 2)
     assert not packed[tab_end - al4(D_ // 2) - al4(20 * D_): tab_end - al4(D_ // 2)].any()      # no positional table
-    enc_total = tab_end + Hd * F + Hd * Hd + 16 + L * stride   # split-pair copies, head scales (unused by this surrogate), fp16 fragments
+    enc_total = tab_end + Hd * F + Hd * Hd + Hd + 16 + L * stride   # split-pair copies + folded bias, head scales (unused by this surrogate), fp16 fragments
     # backward operands of layer 1: Wo^T and W2^T, fragment-major
     per_layer = 32 * 2 * 3 * D_ + 32 * 2 * D_ + 32 * 2 * dff + 32 * D_      # frag_floats(rows, K) = ceil(rows/32)*32*K
     b1 = enc_total + per_layer
