@@ -28,6 +28,7 @@
 #pragma once
 #include "dnag_common.h"
 #include "dnag_encoder.hip.h"
+#include <type_traits>
 
 // Two queries per thread as scalar pairs; the compiler's SLP pass turns most of these pairs into v_pk_fma_f32 /
 // v_pk_mul_f32 / v_pk_add_f32 with op_sel broadcasts on its own (244 packed instructions in the production ISA).
@@ -51,7 +52,7 @@ struct Enc8Geom {
     static constexpr int FS = DFF + 4;          // split hidden rows (DFF values = DFF dwords)
     static constexpr int BIG = R * FS + R * AS; // hidden, then the embedding's staging rows / the row statistics (qkv [R][QS] aliases the front)
     static_assert(R * QS + 4 * R <= BIG, "q|k|v aliases the hidden region; the row statistics [R][2][2] sit behind it");
-    static constexpr int VEC = 3 * D + D + DFF + D;   // staged per layer: bqkv' | bo | b1' | b2
+    static constexpr int VEC = 8 + 3 * D + D + DFF + D;   // staged per layer: scales (CateLayout::l_sc, 8) | bqkv' | bo | b1' | b2
     static constexpr size_t lds_floats = (size_t)R * AS + BIG + (size_t)G * N * N + VEC;
 };
 
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     float *emb = big + 1024;                 // [R][AS] fp32 staging of the embedding (before layer 0 only; behind the staged x)
     float *rst = big + R * QS;               // [R][2 column tiles][mean, M2]: 32-column row statistics, exchanged between the two waves of a row tile
     float *maskb = big + Ge::BIG;            // [G][N][N]
-    float *bst = maskb + G * N * N;          // this layer's bias vectors: bqkv' [192] | bo [64] | b1' [128] | b2 [64]
+    float *scl = maskb + G * N * N;          // this layer's scales (ENC_SC_*), staged with the vectors: a global load in a phase would
+                                             // wait, in order, behind every weight prefetch in flight
+    float *bst = scl + 8;                    // this layer's bias vectors: bqkv' [192] | bo [64] | b1' [128] | b2 [64]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -96,13 +99,20 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     long long ts_[128];
     int nts_ = 0;
 #define E8_STAMP() do { if (nts_ < 128) ts_[nts_++] = __builtin_readcyclecounter(); } while (0)
+    // sub-phase stamps of layer 5, every wave: 'S' = a point inside a phase (pinned), printed relative to the phase's first stamp
+    long long sb_[24];
+    int nsb_ = 0;
+    const long long wc0_ = wall_clock64();       // constant 100 MHz
+#define E8_SUB() do { if (l == 5 && nsb_ < 24) { __builtin_amdgcn_sched_barrier(0); sb_[nsb_++] = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define E8_STAMP()
+#define E8_SUB()
 #endif
     E8_STAMP();
     const int tnt = wave >> 1, tmt = wave & 1;
-    // P1: jobs j = 3 wave .. 3 wave + 2 over (nt = j / 2, mt = j % 2): column tiles q0 (first) and q0 + 1
-    const int q0 = (3 * wave) >> 1;
+    // P1: three of the 6 x 2 (column tile, row tile) jobs per wave: column tile `wave` (weights in bP) for both row tiles,
+    // column tile qx = 4 + wave / 2 (bQ) for row tile wave & 1 -- the same straight-line code for every wave
+    const int qx = 4 + (wave >> 1);
 
     // weight fragments in registers, fetched a phase or more ahead of their use (issue points pinned by the asm)
     float bP[D / 2], bQ[D / 2], bR[DFF / 2];
@@ -114,10 +124,24 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         asm volatile("" : "+s"(W));
         load_frag<DFF>(W, nt, b);
     };
+    // The vectors of a layer (CateLayout::l_vec) are fetched one 16-byte piece per thread well ahead (stage_fetch: before
+    // the loop, then behind P5 of the layer before) and parked in LDS at the start of P0 (stage_put), so no epilogue
+    // waits for a global load that queues behind the weight prefetches.
+    constexpr int NST = Ge::VEC / 4;
+    v4f st4 = {0.f, 0.f, 0.f, 0.f};
+    auto stage_fetch = [&](int tid, int lstage) {
+        // every thread loads (the surplus ones piece 0): a load under a condition leaves the compiler without an exact count
+        // of the loads in flight, and every later s_waitcnt vmcnt falls back to waiting for (nearly) all of them
+        st4 = *reinterpret_cast<const v4f *>(P + lay.layer0 + (size_t)lstage * lay.layer_stride + lay.l_sc + 4 * (tid < NST ? tid : 0));      // l_vec follows l_sc
+    };
+    auto stage_put = [&](int tid) {
+        if (tid < NST) *reinterpret_cast<v4f *>(scl + 4 * tid) = st4;
+    };
+    stage_fetch(tid, 0);                     // ahead of the weight fetches, as in the loop (in-order vmcnt accounting)
     {
         const float *W = P16 + lay.layer0 + lay.l_wqkv;
-        fetch64(W, q0, bP);
-        fetch64(W, q0 + 1, bQ);
+        fetch64(W, wave, bP);
+        fetch64(W, qx, bQ);
     }
 
     // ---- stage inputs ---------------------------------------------------------------------------
@@ -159,23 +183,11 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         hacc[4 * gq + 0] = v.x; hacc[4 * gq + 1] = v.y; hacc[4 * gq + 2] = v.z; hacc[4 * gq + 3] = v.w;
     }
 
-    // The vectors of a layer (CateLayout::l_vec) are fetched one 16-byte piece per thread well ahead (stage_fetch: before
-    // the loop, then behind P5 of the layer before) and parked in LDS at the start of P0 (stage_put), so no epilogue
-    // waits for a global load that queues behind the weight prefetches.
-    constexpr int NST = Ge::VEC / 4;
-    v4f st4 = {0.f, 0.f, 0.f, 0.f};
-    auto stage_fetch = [&](int lstage) {
-        if (tid < NST) st4 = *reinterpret_cast<const v4f *>(P + lay.layer0 + (size_t)lstage * lay.layer_stride + lay.l_vec + 4 * tid);
-    };
-    auto stage_put = [&](int lstage) {
-        (void)lstage;
-        if (tid < NST) *reinterpret_cast<v4f *>(bst + 4 * tid) = st4;
-    };
     // Row statistics of h, first half (behind the phase that produced hacc): mean and centred sum of squares of the
     // lane's 16 values, merged with the other lane half (the tile's other 16 columns of the same row), parked in LDS for
     // the wave that holds the row's other column tile.  own_m / own_q keep this tile's pair.
     float own_m = 0.f, own_q = 0.f;
-    auto stats_put = [&]() {
+    auto stats_put = [&](int r, int h) {
         float s_ = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) s_ += hacc[i];
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         if (h == 0) *reinterpret_cast<float2 *>(rst + ((tmt * 32 + r) * 2 + tnt) * 2) = float2{own_m, own_q};
     };
     // second half (behind the barrier): the other tile's pair -> mean and 1 / std of the 64-wide row
-    auto stats_get = [&](float &mean, float &rstd) {
+    auto stats_get = [&](int r, float &mean, float &rstd) {
         const float2 o = *reinterpret_cast<const float2 *>(rst + ((tmt * 32 + r) * 2 + (tnt ^ 1)) * 2);
         // merged in a fixed order (tile 0 first) so that both waves of a row derive the same bits
         const float m0 = tnt ? o.x : own_m, m1 = tnt ? own_m : o.x, q0 = tnt ? o.y : own_q, q1 = tnt ? own_q : o.y;
@@ -206,9 +218,9 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     // LN(h) * 16 of the wave's registers as split-pair quads into A16.  These rows are both the next layer's QKV operand
     // and -- the affine of the output norm being folded into final.linears.0 (CateLayout::f0_s) -- the concat slice of
     // the layer that just ended, which concat_out copies to HBM.
-    auto norm_write = [&]() {
+    auto norm_write = [&](int r, int h) {
         float mean, rstd;
-        stats_get(mean, rstd);
+        stats_get(r, mean, rstd);
         const int row = tmt * 32 + r;
         rstd *= 16.0f;
 #pragma unroll
@@ -228,74 +240,125 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     // concat slice `lc` = the A16 image, copied out with full 128-byte lines: 64 rows x 2 chunks x 8 pieces of 16 bytes,
     // four pieces per thread (k-tile-blocked rows: dnag_gemm16.hip.h kblock_at).  Runs between the barrier behind P0 and
     // the one behind P1 (P2 is the next writer of A16).
-    auto concat_out = [&](int lc) {
+    auto concat_read = [&](int tid, v4f (&cc)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int pc = tid + 256 * k, row = pc >> 4, dw = (pc & 15) * 4;
-            if (g0 + row / N < batch) {
-                const v4f v = *reinterpret_cast<const v4f *>(a16 + row * AS + dw);
-                *reinterpret_cast<v4f *>(concat + kblock_at((size_t)g0 * N + row, (size_t)lc * D + dw, rows_pad)) = v;
+            cc[k] = *reinterpret_cast<const v4f *>(a16 + row * AS + dw);
+        }
+    };
+    auto concat_write = [&](int tid, const v4f (&cc)[4], int lc) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int pc = tid + 256 * k, row = pc >> 4, dw = (pc & 15) * 4;
+            // unconditional, for the same reason as stage_fetch: rows of graphs beyond the batch are pad rows of the concat
+            // (rows_pad >= 64 * gridDim.x), finite (their x is zero) and read by no one
+            *reinterpret_cast<v4f *>(concat + kblock_at((size_t)g0 * N + row, (size_t)lc * D + dw, rows_pad)) = cc[k];
+        }
+    };
+    // ---- tile jobs.  All A fragments of a 32-row tile (K = 64: four k steps x hi, lo) are read from LDS BEFORE the
+    // accumulation chain starts and the chain is one run of dependent MFMAs (a single chain issues back to back at the
+    // matrix cores' rate); the compiler's own order -- two reads, wait, three MFMAs, per k step -- exposed the LDS latency
+    // in every step (round 3 stamps: P1 3.4 k cycles for 36 MFMAs = 1.15 k).  The empty asm statements pin that order.
+    typedef h8 afrag_t[4][2];
+    auto load_a64 = [&](const float *ap, afrag_t &a) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            a[s][0] = *reinterpret_cast<const h8 *>(ap + 8 * s);
+            a[s][1] = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
+        }
+    };
+    // acc += A W^T over K = 64 (SWAP: the transposed tile, lane = batch row, registers = columns)
+    auto chain64 = [&](const afrag_t &a, const float *b, f32x16 &acc, auto swap) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int o = 8 * s;
+            const h8 bhi = __builtin_bit_cast(h8, v4f{b[o], b[o + 1], b[o + 2], b[o + 3]});
+            const h8 blo = __builtin_bit_cast(h8, v4f{b[o + 4], b[o + 5], b[o + 6], b[o + 7]});
+            if constexpr (decltype(swap)::value) {
+                acc = mfma16(bhi, a[s][0], acc);
+                acc = mfma16(blo, a[s][0], acc);
+                acc = mfma16(bhi, a[s][1], acc);
+            } else {
+                acc = mfma16(a[s][0], bhi, acc);
+                acc = mfma16(a[s][0], blo, acc);
+                acc = mfma16(a[s][1], bhi, acc);
             }
         }
     };
-    stats_put();
-    stage_fetch(0);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+// lane ids derived afresh in every phase: with one set for the whole kernel the compiler hoists every phase's address
+// arithmetic out of the layer loop and keeps (or spills) some sixty registers of loop invariants
+#define E8_IDS() int tid_ = threadIdx.x; asm volatile("" : "+v"(tid_)); const int tid = tid_, r = tid_ & 31, h = (tid_ >> 5) & 1; (void)tid; (void)r; (void)h
+#define E8_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    stats_put(r, h);
     E8_STAMP();
+    // Two workgroups share a CU (256 CUs x 2 at B = 4096) and the wave arbiter serves the older wave first: the first 256
+    // workgroups ran 115 us, their younger partners 145 (wall-clock stamps, round 3).  The two generations (bit 8 of the
+    // workgroup index: the dispatcher hands the workgroups of an XCD, index / 8, to its 32 CUs in order) swap the raised
+    // priority every layer, so that both advance at the same rate and neither is left to finish alone.
+    const int gen = (blockIdx.x >> 8) & 1;
     for (int l = 0; l <= L; ++l) {
+#ifndef ENC8_NO_PRIO
+        if ((l ^ gen) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         // ---- P0: statistics of h -> concat slice l - 1, A16 = LN1(h) -----------------------------------
         __syncthreads();                     // the statistics of both column tiles are in LDS; every reader of A16 / bst is done
         E8_STAMP();
-        if (l < L) stage_put(l);
-        norm_write();
+        {
+            E8_IDS();
+            if (l < L) stage_put(tid);
+            norm_write(r, h);
+        }
         if (l == L) {
             __syncthreads();
-            concat_out(L - 1);
+            v4f cc[4];
+            concat_read(tid, cc);
+            concat_write(tid, cc, L - 1);
             break;
         }
-        const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
         const float *LP16 = P16 + lay.layer0 + (size_t)l * lay.layer_stride;
-        const float *SC = LP + lay.l_sc;
+        const float *SC = scl;
         __syncthreads();
         E8_STAMP();
         // ---- P1: q|k|v (and the concat slice of the layer before: the rows P1 reads) -----------------------
-        if (l > 0) concat_out(l - 1);
         {
+            E8_IDS();
             const float inv = SC[ENC_SC_INV_QKV];
             const float *bias = bst;
-            auto job = [&](const float (&b)[D / 2], int nt, int mt) {
-                const float *ap = a16 + (mt * 32 + r) * AS + h * (D / 2);
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-                for (int s = 0; s < D / 16; ++s) {
-                    const h8 ahi = *reinterpret_cast<const h8 *>(ap + 8 * s);
-                    const h8 alo = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
-                    const int o = 8 * s;
-                    const h8 bhi = __builtin_bit_cast(h8, v4f{b[o], b[o + 1], b[o + 2], b[o + 3]});
-                    const h8 blo = __builtin_bit_cast(h8, v4f{b[o + 4], b[o + 5], b[o + 6], b[o + 7]});
-                    acc = mfma16(ahi, bhi, acc);
-                    acc = mfma16(ahi, blo, acc);
-                    acc = mfma16(alo, bhi, acc);
-                }
+            const int mx = wave & 1;
+            afrag_t xa, ya;
+            v4f cc[4];
+            concat_read(tid, cc);                // unconditional (harmless for l = 0): a conditional read would make cc loop-carried
+            load_a64(a16 + (mx * 32 + r) * AS + h * (D / 2), xa);
+            load_a64(a16 + ((mx ^ 1) * 32 + r) * AS + h * (D / 2), ya);
+            // unconditional as well: layer 0 writes its (meaningless) image into slice 0, which the same threads overwrite
+            // with the real slice one layer later (same wave, same addresses: in order)
+            concat_write(tid, cc, l > 0 ? l - 1 : 0);
+            E8_PIN();
+            auto put = [&](const f32x16 &acc, int nt, int mt) {
                 const int col = nt * 32 + r;
                 const float bv = bias[col];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) qkv[(mt * 32 + acc_row(i, h)) * QS + col] = acc[i] * inv + bv;
             };
-#pragma unroll
-            for (int jj = 0; jj < 3; ++jj) {
-                const int j = 3 * wave + jj;
-                const int nt = j >> 1, mt = j & 1;
-                if (nt == q0) job(bP, nt, mt);       // wave-uniform: a scalar branch, not per-register selects
-                else job(bQ, nt, mt);
-            }
+            f32x16 c1 = zero16, c2 = zero16, c3 = zero16;
+            E8_SUB();
+            chain64(xa, bP, c1, std::false_type{});
+            E8_SUB();
+            chain64(xa, bQ, c3, std::false_type{});
+            put(c1, wave, mx);
+            chain64(ya, bP, c2, std::false_type{});
+            put(c3, qx, mx);
+            put(c2, wave, mx ^ 1);
+            E8_SUB();
         }
         fetch64(LP16 + lay.l_wo, tnt, bP);         // lands while attention runs (P3)
         __syncthreads();
         E8_STAMP();
         // ---- P2: attention, one thread per (graph, head, query pair) ----------------------------------------
         {
+            E8_IDS();
             const int qp = tid & 3, hd = (tid >> 2) & 7, g = tid >> 5;
             const int row0 = g * N + 2 * qp;
             const float sa_o = SC[ENC_SC_SA_O];
@@ -375,62 +438,48 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         E8_STAMP();
         // ---- P3: h += attn Wo^T + bo --------------------------------------------------------------------
         {
+            E8_IDS();
             const float inv = SC[ENC_SC_INV_O];
-            const float *ap = a16 + (tmt * 32 + r) * AS + h * (D / 2);
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < D / 16; ++s) {
-                const h8 ahi = *reinterpret_cast<const h8 *>(ap + 8 * s);
-                const h8 alo = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
-                const int o = 8 * s;
-                const h8 bhi = __builtin_bit_cast(h8, v4f{bP[o], bP[o + 1], bP[o + 2], bP[o + 3]});
-                const h8 blo = __builtin_bit_cast(h8, v4f{bP[o + 4], bP[o + 5], bP[o + 6], bP[o + 7]});
-                acc = mfma16(bhi, ahi, acc);      // D[n][m]: lane = batch row m, registers = columns n (as in P5)
-                acc = mfma16(blo, ahi, acc);
-                acc = mfma16(bhi, alo, acc);
-            }
+            afrag_t xa;
+            load_a64(a16 + (tmt * 32 + r) * AS + h * (D / 2), xa);
+            E8_PIN();
+            f32x16 acc = zero16;
+            E8_SUB();
+            chain64(xa, bP, acc, std::true_type{});     // D[n][m]: lane = batch row m, registers = columns n (as in P5)
+            E8_SUB();
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const v4f b4 = *reinterpret_cast<const v4f *>(bst + 3 * D + tnt * 32 + 8 * gq + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hacc[4 * gq + e] = (acc[4 * gq + e] * inv + b4[e]) + hacc[4 * gq + e];
             }
-            stats_put();
+            stats_put(r, h);
+            E8_SUB();
         }
-        if (l + 1 < L) fetch64(LP16 + lay.layer_stride + lay.l_wqkv, q0, bP);      // next layer's P1
         __syncthreads();
         E8_STAMP();
         // ---- P4: A16 = LN2(h), from the registers ------------------------------------------------------------
-        norm_write();
+        {
+            E8_IDS();
+            norm_write(r, h);
+        }
         __syncthreads();
         E8_STAMP();
         // ---- P5: hidden = relu(LN2(h) W1'^T + b1'), transposed tiles: lane <-> batch row ---------------------
         {
+            E8_IDS();
             const float inv = SC[ENC_SC_INV_F1], sa_f2 = SC[ENC_SC_SA_F2];
             const int nt = wave;
             // the lane's 16 output columns nt*32 + 8 gq + 4 h + (0..3), gq = 0..3
+            const float *b1p = bst + 4 * D + nt * 32 + 4 * h;
+            afrag_t xa, ya;
+            load_a64(a16 + r * AS + h * (D / 2), xa);
+            load_a64(a16 + (32 + r) * AS + h * (D / 2), ya);
             v4f bias4[4];
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) bias4[gq] = *reinterpret_cast<const v4f *>(bst + 4 * D + nt * 32 + 8 * gq + 4 * h);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const float *ap = a16 + (mt * 32 + r) * AS + h * (D / 2);
-                f32x16 acc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-                for (int s = 0; s < D / 16; ++s) {
-                    const h8 ahi = *reinterpret_cast<const h8 *>(ap + 8 * s);
-                    const h8 alo = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
-                    const int o = 8 * s;
-                    const h8 bhi = __builtin_bit_cast(h8, v4f{bQ[o], bQ[o + 1], bQ[o + 2], bQ[o + 3]});
-                    const h8 blo = __builtin_bit_cast(h8, v4f{bQ[o + 4], bQ[o + 5], bQ[o + 6], bQ[o + 7]});
-                    acc = mfma16(bhi, ahi, acc);      // D[n][m]: lane = batch row m, registers = columns n
-                    acc = mfma16(blo, ahi, acc);
-                    acc = mfma16(bhi, alo, acc);
-                }
+            for (int gq = 0; gq < 4; ++gq) bias4[gq] = *reinterpret_cast<const v4f *>(b1p + 8 * gq);
+            E8_PIN();
+            auto put = [&](const f32x16 &acc, int mt) {
                 _Float16 *hrow = reinterpret_cast<_Float16 *>(hid + (mt * 32 + r) * FS);
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
@@ -443,42 +492,85 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                     *reinterpret_cast<h4 *>(dst) = hi;
                     *reinterpret_cast<h4 *>(dst + 8) = lo;
                 }
-            }
+            };
+            f32x16 c0 = zero16, c1 = zero16;
+            E8_SUB();
+            chain64(xa, bQ, c0, std::true_type{});       // D[n][m]: lane = batch row m, registers = columns n
+            E8_SUB();
+            chain64(ya, bQ, c1, std::true_type{});
+            put(c0, 0);
+            put(c1, 1);
+            E8_SUB();
         }
-        if (l + 1 < L) {
-            stage_fetch(l + 1);
-            fetch64(LP16 + lay.layer_stride + lay.l_wqkv, q0 + 1, bQ);
+        {
+            // next layer's P1 (P6 and P0, about 1 us, ahead of their first use; fetched earlier they would hold 64 registers
+            // through P5, whose two jobs want theirs for the A fragments of both row tiles).  The last layer fetches its own
+            // once more: an unconditional, exactly counted prefetch.
+            const float *NP16 = P16 + lay.layer0 + (size_t)(l + 1 < L ? l + 1 : l) * lay.layer_stride;
+            stage_fetch(tid, l + 1 < L ? l + 1 : l);
+            fetch64(NP16 + lay.l_wqkv, wave, bP);
+            fetch64(NP16 + lay.l_wqkv, qx, bQ);
         }
         __syncthreads();
         E8_STAMP();
         // ---- P6: h += hidden W2^T + b2 ------------------------------------------------------------------------
         {
+            E8_IDS();
             const float inv = SC[ENC_SC_INV_F2];
             const float *ap = hid + (tmt * 32 + r) * FS + h * (DFF / 2);
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < DFF / 16; ++s) {
-                const h8 ahi = *reinterpret_cast<const h8 *>(ap + 8 * s);
-                const h8 alo = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
+            // K = 128 = eight k steps in four pairs: two pairs of fragments are in registers before the chain starts, pair
+            // p + 2 is read behind the MFMAs of pair p (into the registers that pair frees)
+            h8 a[8][2];
+            auto ld = [&](int s) {
+                a[s][0] = *reinterpret_cast<const h8 *>(ap + 8 * s);
+                a[s][1] = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
+            };
+            auto mm = [&](int s, f32x16 &acc) {
                 const int o = 8 * s;
                 const h8 bhi = __builtin_bit_cast(h8, v4f{bR[o], bR[o + 1], bR[o + 2], bR[o + 3]});
                 const h8 blo = __builtin_bit_cast(h8, v4f{bR[o + 4], bR[o + 5], bR[o + 6], bR[o + 7]});
-                acc = mfma16(bhi, ahi, acc);
-                acc = mfma16(blo, ahi, acc);
-                acc = mfma16(bhi, alo, acc);
-            }
+                acc = mfma16(bhi, a[s][0], acc);
+                acc = mfma16(blo, a[s][0], acc);
+                acc = mfma16(bhi, a[s][1], acc);
+            };
+            ld(0); ld(1); ld(2); ld(3);
+            E8_PIN();
+            f32x16 acc = zero16;
+            E8_SUB();
+            mm(0, acc); mm(1, acc);
+            E8_SUB();
+            ld(4); ld(5);
+            E8_PIN();
+            mm(2, acc); mm(3, acc);
+            ld(6); ld(7);
+            E8_PIN();
+            mm(4, acc); mm(5, acc);
+            E8_PIN();
+            mm(6, acc); mm(7, acc);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const v4f b4 = *reinterpret_cast<const v4f *>(bst + 4 * D + DFF + tnt * 32 + 8 * gq + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) hacc[4 * gq + e] = (acc[4 * gq + e] * inv + b4[e]) + hacc[4 * gq + e];
             }
-            stats_put();
+            stats_put(r, h);
+            E8_SUB();
         }
     }
 #ifdef ENC8_STAMPS
     if (blockIdx.x == 5 && tid == 0) for (int i = 1; i < nts_; ++i) printf("e8 %d %lld\n", i, ts_[i] - ts_[i - 1]);
+    if ((blockIdx.x % 37) == 5 && tid == 0) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        printf("wg %d xcc %u se %u cu %u : start %lld life %lld x10ns, %lld cycles\n", (int)blockIdx.x, xcc & 15, (hwid >> 13) & 7, (hwid >> 8) & 15, wc0_, wall_clock64() - wc0_, ts_[nts_ - 1] - ts_[0]);
+    }
+    // layer 5's phase stamps are ts_[2 + 7 * 5 + k]: k = 0 P0 start ... 1 P1 start, 3 P3 start, 5 P5 start, 6 P6 start
+    if (blockIdx.x == 5 && lane == 0) {
+        const long long b1 = ts_[2 + 35 + 1], b3 = ts_[2 + 35 + 3], b5 = ts_[2 + 35 + 5], b6 = ts_[2 + 35 + 6];
+        printf("sub wave %d: P1 pre %lld c1 %lld end %lld (next bar %lld) | P3 pre %lld chain %lld end %lld (bar %lld) | P5 pre %lld c0 %lld end %lld (bar %lld) | P6 pre %lld 6mfma %lld end %lld (bar %lld)\n", wave,
+               sb_[0] - b1, sb_[1] - b1, sb_[2] - b1, ts_[2 + 35 + 2] - b1, sb_[3] - b3, sb_[4] - b3, sb_[5] - b3, ts_[2 + 35 + 4] - b3,
+               sb_[6] - b5, sb_[7] - b5, sb_[8] - b5, b6 - b5, sb_[9] - b6, sb_[10] - b6, sb_[11] - b6, ts_[2 + 35 + 7] - b6);
+    }
 #endif
 }

@@ -8,7 +8,7 @@ from diffusionnag_amd import cate  # noqa
 from diffusionnag_amd.specs import CateDims
 from tests.helpers import score_config
 dev = torch.device("cuda:0")
-B = 4096
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 dims = CateDims()
 model = mutils.create_model(score_config(dims, dev)); model.load_state_dict(synthetic.cate_state_dict(dims, 0)); model.eval()
 X = torch.randn(B, 8, 7, device=dev); t = torch.full((1,), 500.0, device=dev)
