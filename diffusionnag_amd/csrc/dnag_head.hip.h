@@ -234,10 +234,23 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
     for (int v = 0; v < V; ++v) red[kq][r][v] = acc[v];
     __syncthreads();
 
+    // fused final.linears.2: the partial sums of the Hd / 256 column blocks, added in block order.  All of them are
+    // requested before the first is used (a loop of load, wait, add cost one memory round trip per block).
+    constexpr int MAXP = 8;
     auto model_out = [&](int rr, int v, size_t e) -> float {
         if (a.parts) {
-            float val = a.parts[e];
-            for (int p = 1; p < a.nparts; ++p) val += a.parts[(size_t)p * a.part_stride + e];
+            float val;
+            if (a.nparts <= MAXP) {
+                float pv[MAXP];
+#pragma unroll
+                for (int p = 0; p < MAXP; ++p) pv[p] = a.parts[(size_t)(p < a.nparts ? p : 0) * a.part_stride + e];
+                val = pv[0];
+#pragma unroll
+                for (int p = 1; p < MAXP; ++p) if (p < a.nparts) val += pv[p];
+            } else {
+                val = a.parts[e];
+                for (int p = 1; p < a.nparts; ++p) val += a.parts[(size_t)p * a.part_stride + e];
+            }
             return val + b3[v];
         }
         return ((red[0][rr][v] + red[1][rr][v]) + (red[2][rr][v] + red[3][rr][v])) + b3[v];
@@ -274,15 +287,21 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
         }
         __syncthreads();
     }
-    // one thread per (row, v) element of this block
+    // one thread per (row, v) element of this block.  Every global read of an element is issued up front and without a
+    // condition (an absent operand reads b3[0] instead; threads beyond the batch read element 0): the reads then overlap
+    // instead of costing one memory round trip each behind the branches that select them.
+    const bool upd = a.mode != EXIT_FORWARD && a.mode != EXIT_CORRECTOR;
     for (int i = tid; i < 64 * V; i += 256) {
         const int rr = i / V, v = i - rr * V;
         const int g = rr / N;
         const bool valid = rr < R && (blockIdx.x * GF + g) < a.batch;
+        const size_t e = valid ? (size_t)(row0 + rr) * V + v : 0;
+        const float val = model_out(valid ? rr : 0, v, e);
+        const float cg = (a.cgrad ? a.cgrad : b3)[a.cgrad ? e : 0];
+        const float nzin = (a.noise ? a.noise : b3)[a.noise ? e : 0];
+        const float xv = (upd ? a.x : b3)[upd ? e : 0];
         float total = 0.f, noise = 0.f;
         if (valid) {
-            const size_t e = (size_t)(row0 + rr) * V + v;
-            const float val = model_out(rr, v, e);
             if (a.mode == EXIT_FORWARD) {
                 if (a.out_gstride) a.out[(size_t)(blockIdx.x * GF + g) * a.out_gstride + (rr - g * N) * V + v] = val;
                 else a.out[e] = val;
@@ -290,7 +309,6 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
                 const float score = a.score_mode == DNAG_SCORE_VP ? __fdiv_rn(-val, a.std) : val;   // models/utils.py:103 | :116
                 total = score;
                 if (a.cgrad != nullptr) {
-                    const float cg = a.cgrad[e];
                     float w = a.cscale;
                     if (a.wr_mode == 1) w = mul_rn(w, gratio[g]);                                        // MBV3 sampling.py:886
                     else if (a.wr_mode == 2) w = mul_rn(w, __fdiv_rn(fabsf(score), fabsf(cg)));        // :890-891
@@ -298,12 +316,11 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float *__restrict__
                 }
                 if (a.rec_score) a.rec_score[e] = score;
                 if (a.rec_total) a.rec_total[e] = total;
-                noise = a.noise ? a.noise[e] : philox_normal(a.seed, a.stream_offset + e, a.draw);
+                noise = a.noise ? nzin : philox_normal(a.seed, a.stream_offset + e, a.draw);
                 if (a.mode == EXIT_CORRECTOR) {
                     a.gbuf[e] = total;
                 } else {
                     // f = sqrt(alpha) x - x ; rev_f = f - G^2 total ; x_mean = x - rev_f ; x = x_mean + G z
-                    const float xv = a.x[e];
                     float xm;
                     if (a.pred_kind == DNAG_PREDICTOR_EULER_MARUYAMA) {
                         // drift = c x - diffusion^2 total ; x_mean = x + drift dt ; x = x_mean + diffusion sqrt(-dt) z
@@ -375,8 +392,19 @@ __device__ __forceinline__ float block_sum_256(float v, float *sh) {
 }
 
 __global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
-    __shared__ float sh[256];
+    __shared__ float sh[256], sh2[256];
     const int tid = threadIdx.x;
+    // the element operands do not depend on the step size: requested (and the noise drawn) before the reduction, whose
+    // barriers then hide their latency.  Unconditional reads (an absent tape reads gbuf; threads past the end element 0).
+    auto fetch = [&](size_t e, float &xv, float &gv, float &nz) {
+        const size_t ec = e < a.nelem ? e : 0;
+        xv = a.x[ec]; gv = a.gbuf[ec];
+        const float nzin = (a.noise ? a.noise : a.gbuf)[ec];
+        nz = a.noise ? nzin : philox_normal(a.seed, a.stream_offset + ec, a.draw);
+    };
+    size_t e = (size_t)blockIdx.x * 256 + tid;
+    float xv, gv, nz;
+    fetch(e, xv, gv, nz);
     float sg = 0.f, sn = 0.f;
     // block k of the (global) batch: segment k / seg, entry k % seg; the order of the sums depends on k alone, so a
     // batch cut into equal shards reduces exactly like the whole batch
@@ -386,8 +414,15 @@ __global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
         sg += a.partials[(size_t)s_ * 2 * seg + j];
         sn += a.partials[(size_t)s_ * 2 * seg + seg + j];
     }
-    const float grad_norm = block_sum_256(sg, sh) / (float)a.batch;
-    const float noise_norm = block_sum_256(sn, sh) / (float)a.batch;
+    // both sums ride on one tree (each with the pairing of block_sum_256: the same bits, half the barriers)
+    sh[tid] = sg; sh2[tid] = sn;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) { sh[tid] = sh[tid] + sh[tid + s]; sh2[tid] = sh2[tid] + sh2[tid + s]; }
+        __syncthreads();
+    }
+    const float grad_norm = sh[0] / (float)a.batch;
+    const float noise_norm = sh2[0] / (float)a.batch;
     // step_size = (snr * noise_norm / grad_norm) ** 2 * 2 * alpha
     const float ratio = __fdiv_rn(mul_rn(a.snr, noise_norm), grad_norm);
     const float step = mul_rn(mul_rn(mul_rn(ratio, ratio), 2.0f), a.alpha);
@@ -395,12 +430,13 @@ __global__ __launch_bounds__(256) void corrector_update_kernel(CorrArgs a) {
     if (blockIdx.x == 0 && tid == 0 && a.rec_step) {
         a.rec_step[0] = grad_norm; a.rec_step[1] = noise_norm; a.rec_step[2] = step;
     }
-    for (size_t e = (size_t)blockIdx.x * 256 + tid; e < a.nelem; e += (size_t)gridDim.x * 256) {
-        const float noise = a.noise ? a.noise[e] : philox_normal(a.seed, a.stream_offset + e, a.draw);
-        const float xm = __fadd_rn(a.x[e], mul_rn(step, a.gbuf[e]));
-        const float xn = __fadd_rn(xm, mul_rn(nscale, noise));
+    while (e < a.nelem) {
+        const float xm = __fadd_rn(xv, mul_rn(step, gv));
+        const float xn = __fadd_rn(xm, mul_rn(nscale, nz));
         a.x[e] = xn;
         if (a.rec_x) a.rec_x[e] = xn;
+        e += (size_t)gridDim.x * 256;
+        if (e < a.nelem) fetch(e, xv, gv, nz);
     }
 }
 

@@ -99,12 +99,12 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     const int TS = lay.hs16 + 4;             // row stride of tv (== 4 mod 16: the rows of a ds_read_b128 spread over the banks)
     static_assert((PRED_MAXHS + 4) * G <= 64 * PRED_HS, "tv fits behind the two 32-row head buffers");
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const int g0 = blockIdx.x * G;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr bool two = true;                           // every wave has two row tiles (the single-tile path is kept for odd splits)
     const int ct = wv >> 1, mt0 = 2 * (wv & 1);          // column tile, first of the two row tiles
-    const int ln = tid & 63, lr = ln & 31, lh = ln >> 5;
+    int ln = tid & 63, lr = ln & 31, lh = ln >> 5;
 #ifdef DNAG_PRED_STAMPS
     long long ts_[64];
     int nts_ = 0;
@@ -137,10 +137,23 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     const float *MIXS = P + lay.mixs;
 
     // tile row rho = 8q + 4h + e  <->  row 16h + 4q + e of the tile's 32 buffer rows (graph 2h + (q >> 1), node 4 (q & 1) + e)
-    const int prow = 16 * ((lr >> 2) & 1) + 4 * (lr >> 3) + (lr & 3);
-    const int row0 = mt0 * 32 + prow, row1 = two ? row0 + 32 : row0;   // this lane's buffer rows in the wave's tile(s)
-    const bool mix_active = lh == ((lr >> 2) & 1);                   // B operand of the mixing: see mixf
-    const int mix_step = lr >> 4;
+    int prow = 16 * ((lr >> 2) & 1) + 4 * (lr >> 3) + (lr & 3);
+    int row0 = mt0 * 32 + prow, row1 = two ? row0 + 32 : row0;       // this lane's buffer rows in the wave's tile(s)
+    bool mix_active = lh == ((lr >> 2) & 1);                         // B operand of the mixing: see mixf
+    int mix_step = lr >> 4;
+    // The lane ids are derived afresh at the top of every layer iteration (through an opaque asm): with one set for the
+    // whole kernel the compiler hoists each phase's address arithmetic out of the loops, runs out of its 168 registers
+    // and reloads the spilled addresses inside the GEMM loops -- each reload behind an s_waitcnt vmcnt(0) that also drains
+    // the weight ring.
+    auto refresh_ids = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));
+        tid = t; ln = t & 63; lr = ln & 31; lh = ln >> 5;
+        prow = 16 * ((lr >> 2) & 1) + 4 * (lr >> 3) + (lr & 3);
+        row0 = mt0 * 32 + prow; row1 = two ? row0 + 32 : row0;
+        mix_active = lh == ((lr >> 2) & 1);
+        mix_step = lr >> 4;
+    };
 
     // ---- weight-fragment ring --------------------------------------------------------------------
     // stream k: fwd layers 1..L-1 (W1^T, W2^T), then bwd layers L-1..1 (W1, W2), then layer 0 bwd (column tile 0 only)
@@ -150,7 +163,10 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         const int kk = k - nfwd;
         if (kk < nfwd) { const int l = L - 1 - (kk >> 1); return P16 + ((kk & 1) ? lay.w2b[l] : lay.w1b[l]); }
         if (kk < nfwd + 2 && ct == 0) return P16 + ((kk & 1) ? lay.w2b[0] : lay.w1b[0]);
-        return nullptr;
+        // past the end (and layer 0's backward matrices for the waves that do not use them): a valid dummy.  Every ring
+        // load is issued unconditionally -- with a load under a condition the compiler loses count of the loads in
+        // flight and every later s_waitcnt vmcnt drains the whole ring.
+        return P16 + lay.w1f[1];
     };
     v4f rb[3][2];                            // [slot][hi | lo]: fragments of three consecutive 16-k steps
 #pragma unroll
@@ -161,10 +177,8 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
         rb[slot][1] = *(gv4p)(p + 256);
     };
     auto ring_prime = [&](const float *F) {
-        if (F != nullptr) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) ring_load(F, s, s);
-        }
+        for (int s = 0; s < 3; ++s) ring_load(F, s, s);
     };
     // Two 32x32 output tiles (the wave's row tiles) against stream `Fc`, K = 144: acc_t = A_t B^T.  The ring holds steps
     // 0..2 of Fc at entry and steps 0..2 of `Fn` (if any) at exit.  The A rows are split-pair rows of Hb.
@@ -201,7 +215,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                 acc1 = mfma16(af[cur][3], bh, acc1);
             }
             if (s + 3 < GH / 16) ring_load(Fc, s + 3, slot);
-            else if (Fn != nullptr) ring_load(Fn, s + 3 - GH / 16, slot);
+            else ring_load(Fn, s + 3 - GH / 16, slot);
             asm volatile("" ::: "memory");
         }
     };
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
 #pragma unroll
     for (int i = 0; i < 16; ++i) h1[i] = 0.f;           // waves with one row tile never touch tile 1
     for (int l = 0; l < L; ++l) {
+        refresh_ids();
         f32x16 r0, r1;                       // relu(Z1)
         uint32_t w0 = 0u, w1 = 0u;
 #pragma unroll
@@ -416,6 +431,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
 
     // ---- head forward: graphs become the rows 0..G-1 of a 32-row MFMA tile ---------------------------
     {
+        refresh_ids();
         // node sum of a graph = sum over lane bits 0, 1, 3 of rho' (digcn_meta.py:19-22)
         float vmax = 0.f;
 #pragma unroll
@@ -424,6 +440,14 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
             const f32x16 &hv = t ? h1 : h0;
             const int gi = (mt0 + t) * 4 + 2 * ((lr >> 2) & 1) + (lr >> 4);
             const int gg = (g0 + gi < batch) ? g0 + gi : 0;
+            // the time embedding of the lane's 16 columns, fetched by every lane up front (column clamped): one load per
+            // value inside the condition below cost an L2 round trip each, sixteen in a row
+            v4f te[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c0_ = ct * 32 + 8 * q + 4 * lh;
+                te[q] = *(gv4p)(temb + (size_t)(tstride ? gg : 0) * GH + (c0_ < GH ? c0_ : 0));
+            }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 float s = hv[i];
@@ -432,7 +456,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
                 s += dpp_mov<0x128>(s);     // row_ror 8: lane ^ 8 within the row of 16
                 const int c = ct * 32 + 8 * (i >> 2) + 4 * lh + (i & 3);
                 if ((lr & 11) == 0 && c < GH) {
-                    const float pv = s * (1.0f / (float)N) + temb[(size_t)(tstride ? gg : 0) * GH + c];   // :125
+                    const float pv = s * (1.0f / (float)N) + te[i >> 2][i & 3];   // :125
                     hA[gi * HS + c] = pv;
                     vmax = fmaxf(vmax, fabsf(pv));
                 }
@@ -584,6 +608,7 @@ __global__ __launch_bounds__(PRED_NW * 64) void predictor_kernel(const float *__
     // ---- backward: layers L-1 .. 0 -------------------------------------------------------------------
     sidx = nfwd;
     for (int l = L - 1; l >= 0; --l) {
+        refresh_ids();
         const float sd = slot_scale(AM_DH + l);
         const uint32_t w0 = mbits[(l * 2 + 0) * NT + tid], w1 = mbits[(l * 2 + 1) * NT + tid];
         f32x16 e0, e1;
