@@ -137,13 +137,6 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     auto stage_put = [&](int tid) {
         if (tid < NST) *reinterpret_cast<v4f *>(scl + 4 * tid) = st4;
     };
-    stage_fetch(tid, 0);                     // ahead of the weight fetches, as in the loop (in-order vmcnt accounting)
-    {
-        const float *W = P16 + lay.layer0 + lay.l_wqkv;
-        fetch64(W, wave, bP);
-        fetch64(W, qx, bQ);
-    }
-
     // ---- stage inputs ---------------------------------------------------------------------------
     float *xin = qkv;                        // [R][V] alias
     for (int i = tid; i < R * V; i += 256) {
@@ -247,14 +240,15 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             cc[k] = *reinterpret_cast<const v4f *>(a16 + row * AS + dw);
         }
     };
+    auto concat_write1 = [&](int tid, const v4f &c, int k, int lc) {
+        const int pc = tid + 256 * k, row = pc >> 4, dw = (pc & 15) * 4;
+        // unconditional, for the same reason as stage_fetch: rows of graphs beyond the batch are pad rows of the concat
+        // (rows_pad >= 64 * gridDim.x), finite (their x is zero) and read by no one
+        *reinterpret_cast<v4f *>(concat + kblock_at((size_t)g0 * N + row, (size_t)lc * D + dw, rows_pad)) = c;
+    };
     auto concat_write = [&](int tid, const v4f (&cc)[4], int lc) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int pc = tid + 256 * k, row = pc >> 4, dw = (pc & 15) * 4;
-            // unconditional, for the same reason as stage_fetch: rows of graphs beyond the batch are pad rows of the concat
-            // (rows_pad >= 64 * gridDim.x), finite (their x is zero) and read by no one
-            *reinterpret_cast<v4f *>(concat + kblock_at((size_t)g0 * N + row, (size_t)lc * D + dw, rows_pad)) = cc[k];
-        }
+        for (int k = 0; k < 4; ++k) concat_write1(tid, cc[k], k, lc);
     };
     // ---- tile jobs.  All A fragments of a 32-row tile (K = 64: four k steps x hi, lo) are read from LDS BEFORE the
     // accumulation chain starts and the chain is one run of dependent MFMAs (a single chain issues back to back at the
@@ -268,24 +262,37 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             a[s][1] = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
         }
     };
+    // One 1 KB piece (k step q / 2, hi or lo) of column tile `nt` of a fragment-major matrix into b[4 q ..].  The weight
+    // prefetch is issued piece by piece BEHIND the MFMAs of the accumulation chains (hook(i) runs after MFMA i of a chain):
+    // the eight waves of a CU share one 64 B/clk path from the L2, a wave that issues 8-17 loads in a row blocks at issue
+    // until the queue drains, and done in front of a barrier (round 3 stamps: 500-1300 cycles per burst) that wait was
+    // the workgroup's; behind an MFMA it overlaps the 36 cycles the dependent chain waits anyway.
+    typedef const __attribute__((address_space(1))) v4f *gv4p_;
+    auto piece = [&](const float *W, int nt, int K, float *b, int q) {
+        const v4f v = *(gv4p_)(W + ((size_t)nt * (K / 8) * 64 + (threadIdx.x & 63)) * 4 + (size_t)q * 256);
+        b[4 * q + 0] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+    };
+    // MFMAs and vector-memory operations keep their program order; VALU, SALU and LDS instructions may move across
+#define E8_HOLD() __builtin_amdgcn_sched_barrier(0x2 | 0x4 | 0x80 | 0x100 | 0x200 | 0x400)
     // acc += A W^T over K = 64 (SWAP: the transposed tile, lane = batch row, registers = columns)
-    auto chain64 = [&](const afrag_t &a, const float *b, f32x16 &acc, auto swap) {
+    auto chain64 = [&](const afrag_t &a, const float *b, f32x16 &acc, auto swap, auto hook) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int o = 8 * s;
             const h8 bhi = __builtin_bit_cast(h8, v4f{b[o], b[o + 1], b[o + 2], b[o + 3]});
             const h8 blo = __builtin_bit_cast(h8, v4f{b[o + 4], b[o + 5], b[o + 6], b[o + 7]});
             if constexpr (decltype(swap)::value) {
-                acc = mfma16(bhi, a[s][0], acc);
-                acc = mfma16(blo, a[s][0], acc);
-                acc = mfma16(bhi, a[s][1], acc);
+                acc = mfma16(bhi, a[s][0], acc); hook(3 * s); E8_HOLD();
+                acc = mfma16(blo, a[s][0], acc); hook(3 * s + 1); E8_HOLD();
+                acc = mfma16(bhi, a[s][1], acc); hook(3 * s + 2); E8_HOLD();
             } else {
-                acc = mfma16(a[s][0], bhi, acc);
-                acc = mfma16(a[s][0], blo, acc);
-                acc = mfma16(a[s][1], bhi, acc);
+                acc = mfma16(a[s][0], bhi, acc); hook(3 * s); E8_HOLD();
+                acc = mfma16(a[s][0], blo, acc); hook(3 * s + 1); E8_HOLD();
+                acc = mfma16(a[s][1], bhi, acc); hook(3 * s + 2); E8_HOLD();
             }
         }
     };
+    auto no_hook = [](int) {};
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 // lane ids derived afresh in every phase: with one set for the whole kernel the compiler hoists every phase's address
 // arithmetic out of the layer loop and keeps (or spills) some sixty registers of loop invariants
@@ -293,6 +300,16 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
 #define E8_PIN() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
     stats_put(r, h);
     E8_STAMP();
+    // First layer's vectors and q|k|v weights, requested HERE and in the loop's own order (vectors, tile `wave`, tile
+    // qx) with no other vector-memory traffic pending: the compiler's s_waitcnt model merges the state at loop entry
+    // with the back edge's, and only identical states let P1 wait for exactly the fragment it needs (fetched at kernel
+    // entry, among the embedding's loads, its first MFMA waited for all but 7 of the 20 operations in flight).
+    {
+        const float *W = P16 + lay.layer0 + lay.l_wqkv;
+        fetch64(W, wave, bP);                // the loop's own order: tile `wave` (behind P5), vectors and tile qx (behind P6)
+        stage_fetch(tid, 0);
+        fetch64(W, qx, bQ);
+    }
     // Two workgroups share a CU (256 CUs x 2 at B = 4096) and the wave arbiter serves the older wave first: the first 256
     // workgroups ran 115 us, their younger partners 145 (wall-clock stamps, round 3).  The two generations (bit 8 of the
     // workgroup index: the dispatcher hands the workgroups of an XCD, index / 8, to its 32 CUs in order) swap the raised
@@ -328,13 +345,8 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             const float *bias = bst;
             const int mx = wave & 1;
             afrag_t xa, ya;
-            v4f cc[4];
-            concat_read(tid, cc);                // unconditional (harmless for l = 0): a conditional read would make cc loop-carried
             load_a64(a16 + (mx * 32 + r) * AS + h * (D / 2), xa);
             load_a64(a16 + ((mx ^ 1) * 32 + r) * AS + h * (D / 2), ya);
-            // unconditional as well: layer 0 writes its (meaningless) image into slice 0, which the same threads overwrite
-            // with the real slice one layer later (same wave, same addresses: in order)
-            concat_write(tid, cc, l > 0 ? l - 1 : 0);
             E8_PIN();
             auto put = [&](const f32x16 &acc, int nt, int mt) {
                 const int col = nt * 32 + r;
@@ -344,16 +356,28 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             };
             f32x16 c1 = zero16, c2 = zero16, c3 = zero16;
             E8_SUB();
-            chain64(xa, bP, c1, std::false_type{});
+            // behind the 36 MFMAs: the 16 pieces of W2 (P6) and, once both jobs on column tile `wave` are issued, the 8 of Wo
+            // (P3) into the registers they free
+            const float *W2p = LP16 + lay.l_w2, *Wop = LP16 + lay.l_wo;
+            chain64(xa, bP, c1, std::false_type{}, [&](int i) { piece(W2p, tnt, DFF, bR, i); });
             E8_SUB();
-            chain64(xa, bQ, c3, std::false_type{});
+            chain64(ya, bP, c2, std::false_type{}, [&](int i) { if (i < 4) piece(W2p, tnt, DFF, bR, 12 + i); });
             put(c1, wave, mx);
-            chain64(ya, bP, c2, std::false_type{});
-            put(c3, qx, mx);
+            // The concat slice of the layer before (= the A16 rows this phase reads) is read once more from LDS here, when the
+            // first two jobs have released their registers, and stored behind the last four MFMAs.  Every store is
+            // unconditional: layer 0 writes its (meaningless) image into slice 0, which the same threads overwrite with
+            // the real slice one layer later (same wave, same addresses: in order).
+            v4f cc[4];
+            concat_read(tid, cc);
+            const int lc = l > 0 ? l - 1 : 0;
+            chain64(xa, bQ, c3, std::false_type{}, [&](int i) {
+                if (i < 8) piece(Wop, tnt, D, bP, i);
+                else concat_write1(tid, cc[i - 8], i - 8, lc);
+            });
             put(c2, wave, mx ^ 1);
+            put(c3, qx, mx);
             E8_SUB();
         }
-        fetch64(LP16 + lay.l_wo, tnt, bP);         // lands while attention runs (P3)
         __syncthreads();
         E8_STAMP();
         // ---- P2: attention, one thread per (graph, head, query pair) ----------------------------------------
@@ -431,9 +455,6 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 *reinterpret_cast<h8 *>(dst + 4) = lo;
             }
         }
-        // fetched behind the attention, whose registers they would otherwise compete for
-        fetch64(LP16 + lay.l_w1, wave, bQ);        // P5
-        fetch128(LP16 + lay.l_w2, tnt, bR);        // P6
         __syncthreads();
         E8_STAMP();
         // ---- P3: h += attn Wo^T + bo --------------------------------------------------------------------
@@ -445,7 +466,9 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             E8_PIN();
             f32x16 acc = zero16;
             E8_SUB();
-            chain64(xa, bP, acc, std::true_type{});     // D[n][m]: lane = batch row m, registers = columns n (as in P5)
+            const float *W1p = LP16 + lay.l_w1;
+            // D[n][m]: lane = batch row m, registers = columns n (as in P5); behind the MFMAs: W1's tile for P5
+            chain64(xa, bP, acc, std::true_type{}, [&](int i) { if (i < 8) piece(W1p, wave, D, bQ, i); });
             E8_SUB();
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
@@ -495,21 +518,16 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             };
             f32x16 c0 = zero16, c1 = zero16;
             E8_SUB();
-            chain64(xa, bQ, c0, std::true_type{});       // D[n][m]: lane = batch row m, registers = columns n
+            // D[n][m]: lane = batch row m, registers = columns n; behind the first job's MFMAs: the next layer's q|k|v tile
+            // `wave` (the last layer fetches its own once more: an unconditional, exactly counted prefetch)
+            const float *NP16 = P16 + lay.layer0 + (size_t)(l + 1 < L ? l + 1 : l) * lay.layer_stride;
+            const float *Wqp = NP16 + lay.l_wqkv;
+            chain64(xa, bQ, c0, std::true_type{}, [&](int i) { if (i < 8) piece(Wqp, wave, D, bP, i); });
             E8_SUB();
-            chain64(ya, bQ, c1, std::true_type{});
+            chain64(ya, bQ, c1, std::true_type{}, no_hook);
             put(c0, 0);
             put(c1, 1);
             E8_SUB();
-        }
-        {
-            // next layer's P1 (P6 and P0, about 1 us, ahead of their first use; fetched earlier they would hold 64 registers
-            // through P5, whose two jobs want theirs for the A fragments of both row tiles).  The last layer fetches its own
-            // once more: an unconditional, exactly counted prefetch.
-            const float *NP16 = P16 + lay.layer0 + (size_t)(l + 1 < L ? l + 1 : l) * lay.layer_stride;
-            stage_fetch(tid, l + 1 < L ? l + 1 : l);
-            fetch64(NP16 + lay.l_wqkv, wave, bP);
-            fetch64(NP16 + lay.l_wqkv, qx, bQ);
         }
         __syncthreads();
         E8_STAMP();
@@ -525,13 +543,20 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 a[s][0] = *reinterpret_cast<const h8 *>(ap + 8 * s);
                 a[s][1] = *reinterpret_cast<const h8 *>(ap + 8 * s + 4);
             };
+            // behind the MFMAs: the next layer's vectors and its q|k|v tile qx (bQ is free since P5)
+            const int ln_ = l + 1 < L ? l + 1 : l;
+            const float *Wqp = P16 + lay.layer0 + (size_t)ln_ * lay.layer_stride + lay.l_wqkv;
+            auto hook = [&](int i) {
+                if (i == 0) stage_fetch(tid, ln_);
+                else if (i <= 8) piece(Wqp, qx, D, bQ, i - 1);
+            };
             auto mm = [&](int s, f32x16 &acc) {
                 const int o = 8 * s;
                 const h8 bhi = __builtin_bit_cast(h8, v4f{bR[o], bR[o + 1], bR[o + 2], bR[o + 3]});
                 const h8 blo = __builtin_bit_cast(h8, v4f{bR[o + 4], bR[o + 5], bR[o + 6], bR[o + 7]});
-                acc = mfma16(bhi, a[s][0], acc);
-                acc = mfma16(blo, a[s][0], acc);
-                acc = mfma16(bhi, a[s][1], acc);
+                acc = mfma16(bhi, a[s][0], acc); hook(3 * s); E8_HOLD();
+                acc = mfma16(blo, a[s][0], acc); hook(3 * s + 1); E8_HOLD();
+                acc = mfma16(bhi, a[s][1], acc); hook(3 * s + 2); E8_HOLD();
             };
             ld(0); ld(1); ld(2); ld(3);
             E8_PIN();
@@ -540,12 +565,11 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             mm(0, acc); mm(1, acc);
             E8_SUB();
             ld(4); ld(5);
-            E8_PIN();
+            E8_HOLD();
             mm(2, acc); mm(3, acc);
             ld(6); ld(7);
-            E8_PIN();
+            E8_HOLD();
             mm(4, acc); mm(5, acc);
-            E8_PIN();
             mm(6, acc); mm(7, acc);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
