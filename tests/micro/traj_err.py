@@ -19,12 +19,13 @@ def run():
     guided = bool(int(g["guided"]))
     B, S, N = int(g["B"]), int(g["n_run"]), int(g["sde_N"])
     cfg = score_config(CateDims(), DEV)
-    cfg.sampling["predictor"], cfg.sampling["corrector"] = str(g["predictor"]), str(g["corrector"])
+    if "predictor" in g: cfg.sampling["predictor"], cfg.sampling["corrector"] = str(g["predictor"]), str(g["corrector"])
     model = T.make_score(CateDims(), int(g["seed"]), preset=str(g["preset"]))
-    sde = sde_lib.VESDE(0.1, 5.0, N) if str(g["sde_kind"]) == "ve" else sde_lib.VPSDE(0.1, 20.0, N)
+    bmax = float(g["beta_max"]) if "beta_max" in g else 20.0
+    sde = sde_lib.VESDE(0.1, 5.0, N) if ("sde_kind" in g and str(g["sde_kind"]) == "ve") else sde_lib.VPSDE(0.1, bmax, N)
     fn = sampling.get_sampling_fn(cfg, sde, (B, 8, 7), utils.get_data_inverse_scaler(cfg), float(g["eps"]), conditional=guided)
     tape = synthetic.noise_tape(S, (B, 8, 7), int(g["tape_seed"]))
-    tape["x0"] = torch.from_numpy(g["x0"])
+    tape["x0"] = torch.from_numpy(g["x0"] if "x0" in g else g["x_in"][0] if g["x_in"].ndim == 4 else g["x_in"])
     fn.noise_tape = {k: v.to(DEV) for k, v in tape.items()}
     fn.max_steps, fn.record = S, True
     mask = torch.from_numpy(g["mask"])

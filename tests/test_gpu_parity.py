@@ -2,9 +2,10 @@
 reference (tests/golden/*.npz) and with the CPU oracle on seeded inputs.  Needs an MI355X.
 
 Tolerances (fp32 path, different summation order than the CPU reference): single evaluations
-5e-6 of the tensor's max; teacher-free trajectories grow that error with the trajectory's own
-sensitivity, so later steps are checked to 2e-4 of the state's max, and the discretised
-architectures (threshold at 0.5) must match bit for bit."""
+5e-6 of the tensor's max.  Complete trajectories on the contractive presets keep that tolerance at every
+step (measured 2e-7 .. 1.2e-6 over 100 steps); the N=1000 run (2000 free-running evaluations) ends
+2.7e-4 away and is held to 1e-3; random-init trajectories amplify rounding by 1e2 .. 1e5 and are judged
+by the decision-margin test.  The discretised architectures (threshold at 0.5) must match bit for bit."""
 
 import numpy as np
 import pytest
@@ -27,6 +28,7 @@ def close(a, b, rel, what=""):
     e = np.abs(a - b).max()
     scale = np.abs(b).max()
     assert e <= rel * scale + 1e-30, f"{what}: max|err| {e:.3e} > {rel:.1e} * {scale:.3e}"
+    return e / (scale + 1e-30)
 
 
 def kink_tolerant_cgrad(ours, sdp, x_in, vec_t, masks, D_mu, sde, what):
@@ -231,12 +233,18 @@ def test_pc_first_steps_random_init(name, guided):
 
 @pytest.mark.parametrize("name,guided", [("pc_uncond_nb201_contractive_n100", False), ("pc_guided_nb201_contractive_n100", True)])
 def test_pc_full_trajectory_contractive(name, guided):
+    """Complete N=100 trajectories against the reference's record.  The tolerance grows with the step because the
+    contractive presets do not amplify rounding differences, so every step is held to the single-evaluation tolerance
+    (measured, printed below: 2e-7 at step 0 to 1.2e-6 at step 99 for the state, 6e-7 to 9e-7 for the score).  The
+    sampling encoder itself is held to 2e-6 of the generic one (test_sampling_encoder_matches_generic_encoder)."""
     g = golden(name)
     final, r = run_sampler(g, guided)
-    for i in (0, 1, 10, 50, 99):
-        close(r["rec_x_pred"][i], g["x_pred"][i], 2e-4, f"x_pred[{i}]")
-        close(r["rec_score_p"][i], g["score_p"][i], 2e-4, f"score_p[{i}]")
-    close(final, g["final"], 2e-4, "final")
+    bounds = {0: 5e-6, 1: 5e-6, 10: 5e-6, 50: 5e-6, 99: 5e-6}
+    for i, tol in bounds.items():
+        ex = close(r["rec_x_pred"][i], g["x_pred"][i], tol, f"x_pred[{i}]")
+        es = close(r["rec_score_p"][i], g["score_p"][i], 1e-5, f"score_p[{i}]")
+        print(f"{name} step {i}: x_pred {ex:.1e} score_p {es:.1e}")
+    close(final, g["final"], 5e-6, "final")
     q = np.stack(utils.quantize(final))
     assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
 
@@ -247,7 +255,8 @@ def test_pc_full_n1000_guided_contractive():
     final, _ = run_sampler(g, True, record=False)
     q = np.stack(utils.quantize(final))
     assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
-    close(final, g["final"], 1e-3, "final")      # 2000 free-running evaluations: fp32 order differences compound
+    e = close(final, g["final"], 1e-3, "final")      # 2000 free-running evaluations: fp32 order differences compound
+    print(f"n1000 guided contractive: final {e:.1e}")
 
 
 def test_pc_full_trajectory_decision_margin():
@@ -816,3 +825,27 @@ def test_vesde_philox_prior_scale_and_score_fn_wrapper():
     ref = O.score_fn(sd, osde, X, t, masks)
     got = mutils.get_score_fn(sde, model, train=False, continuous=True)(X.to(DEV), t.to(DEV), masks.to(DEV))
     close(got, ref, 5e-6, "VE score")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,scale", [(4096, 1.0), (13, 1.0), (512, 30.0)])
+def test_sampling_encoder_matches_generic_encoder(B, scale):
+    """encoder8_kernel (v_rsq_f32 / v_rcp_f32 / __expf, statistics merged pairwise in registers) against the generic
+    encoder_kernel on the same inputs: the kernels' own distance, without any trajectory amplification (the
+    trajectory tolerances alone do not say how much of their slack is kernel error).  Measured 4e-7 (concat) / 6e-7 (head
+    output) of the tensor maximum; the oracle is 1e-6 away from either."""
+    from diffusionnag_amd import mutils, synthetic, utils
+    from diffusionnag_amd.specs import CateDims
+    from tests.helpers import score_config
+    dev = "cuda:0"
+    m = mutils.create_model(score_config(CateDims(), dev)); m.load_state_dict(synthetic.cate_state_dict(CateDims(), seed=0)); m.eval()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = (torch.randn(B, 8, 7, generator=g) * scale).to(dev)
+    t = torch.full((1,), 700.0, device=dev)
+    mk = utils.aug_mask(utils.nb201_adj()).to(dev)
+    ref_out, ref_c, _ = m(X, t, mk, return_concat=True, return_attn0=True)      # attention probabilities: the generic kernel
+    out, c, _ = m(X, t, mk, return_concat=True)                                  # the sampling path: encoder8_kernel
+    ec = float((c - ref_c).abs().max() / ref_c.abs().max())
+    eo = float((out - ref_out).abs().max() / ref_out.abs().max())
+    print(f"encoder8 vs encoder: concat {ec:.2e}, head output {eo:.2e}")
+    assert ec <= 2e-6 and eo <= 2e-6, (ec, eo)
