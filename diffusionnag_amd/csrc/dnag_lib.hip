@@ -1201,7 +1201,10 @@ template <int ACTB>
 static int launch_tn_small(const float *A, int lda, const float *Bm, int ldb, size_t rows, int nz, int I, int J, float *scratch,
                            float *out, hipStream_t st) {
     const int chunk = (int)((rows + nz - 1) / nz);
-    hipLaunchKernelGGL((tn_small_kernel<ACTB>), dim3((I * J + 255) / 256, 1, nz), dim3(256), 0, st, A, lda, Bm, ldb, (int)rows, chunk, I, J, scratch);
+    if (ACTB == 0 && I <= 8)
+        hipLaunchKernelGGL((tn_few_kernel<8>), dim3((J + 255) / 256, 1, nz), dim3(256), 0, st, A, lda, Bm, ldb, (int)rows, chunk, I, J, scratch);
+    else
+        hipLaunchKernelGGL((tn_small_kernel<ACTB>), dim3((I * J + 255) / 256, 1, nz), dim3(256), 0, st, A, lda, Bm, ldb, (int)rows, chunk, I, J, scratch);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((I * J + 255) / 256), dim3(256), 0, st, scratch, nz, (size_t)I * J, (size_t)I * J, out, 1.0f);
     LAUNCH_CHECK();

@@ -168,11 +168,19 @@ __global__ __launch_bounds__(256) void train_scales_kernel(const float *__restri
     // folded row r of W (W diag(gamma)): largest magnitude, and the worst case of |W' u + b'| over LayerNorm outputs u
     auto row_stats = [&](const float *W, const float *b, const float *gam, const float *bet, float &amax, float &bound) {
         float a = 0.f, q = 0.f, bb = *b;
-        for (int k = 0; k < d; ++k) {
-            const float w = W[k] * gam[k];
-            a = fmaxf(a, fabsf(w));
-            q = fmaf(w, w, q);
-            bb = fmaf(W[k], bet[k], bb);
+        // 16-byte loads, four in flight (d is a multiple of 16; the rows, gamma and beta are 16-byte aligned); the sums keep
+        // their element order
+#pragma unroll 4
+        for (int k = 0; k < d; k += 4) {
+            const v4f w4 = *reinterpret_cast<const v4f *>(W + k), g4 = *reinterpret_cast<const v4f *>(gam + k);
+            const v4f b4 = *reinterpret_cast<const v4f *>(bet + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float w = w4[e] * g4[e];
+                a = fmaxf(a, fabsf(w));
+                q = fmaf(w, w, q);
+                bb = fmaf(w4[e], b4[e], bb);
+            }
         }
         amax = a;
         bound = (sqrtf((float)d) * sqrtf(q) + fabsf(bb)) * 1.0001f;
@@ -194,8 +202,16 @@ __global__ __launch_bounds__(256) void train_scales_kernel(const float *__restri
     }
     if (t < d) {
         float a = 0.f, a2 = 0.f;
-        for (int k = 0; k < d; ++k) a = fmaxf(a, fabsf(SL[sl.s_wo + (size_t)t * d + k]));
-        for (int k = 0; k < dff; ++k) a2 = fmaxf(a2, fabsf(SL[sl.s_w2 + (size_t)t * dff + k]));
+#pragma unroll 4
+        for (int k = 0; k < d; k += 4) {
+            const v4f w4 = *reinterpret_cast<const v4f *>(SL + sl.s_wo + (size_t)t * d + k);
+            a = fmaxf(fmaxf(a, fmaxf(fabsf(w4.x), fabsf(w4.y))), fmaxf(fabsf(w4.z), fabsf(w4.w)));
+        }
+#pragma unroll 4
+        for (int k = 0; k < dff; k += 4) {
+            const v4f w4 = *reinterpret_cast<const v4f *>(SL + sl.s_w2 + (size_t)t * dff + k);
+            a2 = fmaxf(fmaxf(a2, fmaxf(fabsf(w4.x), fabsf(w4.y))), fmaxf(fabsf(w4.z), fabsf(w4.w)));
+        }
         note(1, a);
         note(3, a2);
     }
@@ -334,6 +350,28 @@ __global__ __launch_bounds__(256) void tn_small_kernel(const float *__restrict__
     out[(size_t)blockIdx.z * I * J + idx] = acc;
 }
 
+// The same for I <= IMAX rows of output: one thread per column j carries all I sums, so B is read once instead of I
+// times (dW3 = dout^T H2: I = V = 7 against 50 MB of H2).  Per (i, j) the rows are added in the same order as above.
+template <int IMAX>
+__global__ __launch_bounds__(256) void tn_few_kernel(const float *__restrict__ A, int lda, const float *__restrict__ Bm, int ldb,
+                                                     int rows, int chunk, int I, int J, float *__restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= J) return;
+    const int r0 = blockIdx.z * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
+    float acc[IMAX];
+#pragma unroll
+    for (int i = 0; i < IMAX; ++i) acc[i] = 0.f;
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+        const float b = Bm[(size_t)r * ldb + j];
+#pragma unroll
+        for (int i = 0; i < IMAX; ++i) acc[i] = fmaf(A[(size_t)r * lda + (i < I ? i : 0)], b, acc[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < IMAX; ++i)
+        if (i < I) out[(size_t)blockIdx.z * I * J + (size_t)i * J + j] = acc[i];
+}
+
 // out[z][j] = sum over the z-th chunk of rows of A[r][j]
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, int lda, int rows, int chunk, int J,
                                                      float *__restrict__ out) {
@@ -350,10 +388,19 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float *__restri
                                                            float *__restrict__ out, float scale) {
     if (((n | stride) & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
         for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+            // eight slabs requested before the first is added (a thread streams one 16-byte column of up to 256 slabs: with
+            // one load in flight the 614 MB of a training step's slabs moved at 2 TB/s); the additions keep their order
             v4f acc = *reinterpret_cast<const v4f *>(in + i);
-            for (int p = 1; p < nparts; ++p) {
-                const v4f v = *reinterpret_cast<const v4f *>(in + (size_t)p * stride + i);
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            for (int p0 = 1; p0 < nparts; p0 += 8) {
+                v4f v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int p = p0 + k < nparts ? p0 + k : nparts - 1;       // clamped: an unconditional load
+                    v[k] = *reinterpret_cast<const v4f *>(in + (size_t)p * stride + i);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (p0 + k < nparts) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
             }
             acc.x *= scale; acc.y *= scale; acc.z *= scale; acc.w *= scale;
             *reinterpret_cast<v4f *>(out + i) = acc;

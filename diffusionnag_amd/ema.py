@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .flat import chain_view, flatten_
+from .flat import chain_view, flatten_, FlatCache
 
 
 class ExponentialMovingAverage:
@@ -35,7 +35,9 @@ class ExponentialMovingAverage:
         """The shadow parameters as one flat buffer (re-seated as views of it on first use)."""
         if like is not None and self.shadow_params and self.shadow_params[0].device != like[0].device:
             self.shadow_params = [s.to(like[0].device) for s in self.shadow_params]
-        return flatten_(self.shadow_params)
+        if getattr(self, "_flat_cache", None) is None:
+            self._flat_cache = FlatCache()
+        return self._flat_cache.get(self.shadow_params, flatten_)
 
     def update(self, parameters):
         """shadow -= (1 - decay) (shadow - param), decay = min(decay, (1 + n) / (10 + n))  (ema.py:24-42)."""

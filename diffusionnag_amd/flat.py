@@ -41,3 +41,24 @@ def flatten_(tensors: List[torch.Tensor]) -> torch.Tensor:
         t.data = flat[o:o + n].view(t.shape)
         o += n
     return flat
+
+
+class FlatCache:
+    """Remembers the flat view of a fixed list of tensors and re-validates it with two pointer comparisons (first tensor at
+    the buffer's start, last tensor ending at its end) instead of a walk over every tensor: the training step asks for
+    the same views four times per step, and the walk was a quarter of the host's time per step."""
+
+    def __init__(self):
+        self.flat = None
+        self.first = self.last = None
+
+    def get(self, tensors: List[torch.Tensor], make=chain_view) -> Optional[torch.Tensor]:
+        f = self.flat
+        if f is not None and tensors and tensors[0] is self.first and tensors[-1] is self.last:
+            a, b = tensors[0].data, tensors[-1].data
+            if a.data_ptr() == f.data_ptr() and b.data_ptr() + 4 * b.numel() == f.data_ptr() + 4 * f.numel():
+                return f
+        f = make(tensors if make is flatten_ else [t.data for t in tensors])
+        self.flat = f
+        self.first, self.last = (tensors[0], tensors[-1]) if (f is not None and tensors) else (None, None)
+        return f

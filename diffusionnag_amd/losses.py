@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib, sde_lib
-from .flat import chain_view, flatten_
+from .flat import chain_view, flatten_, FlatCache
 from .cate import CATE, Workspace, positional_table, timestep_frequencies
 
 
@@ -53,19 +53,28 @@ class FusedAdam:
             self._ws = torch.empty(_lib.load().dnag_optim_workspace_bytes() // 4, dtype=torch.float32, device=flat.device)
             self.last_grad_norm = torch.zeros(1, dtype=torch.float32, device=flat.device)
 
-    def step(self, grad_clip: float = -1.0, ema=None):
+    def step(self, grad_clip: float = -1.0, ema=None, flat_grads=None):
+        """``flat_grads``: the gradients as one flat buffer in parameter order (the fused training step's own output),
+        instead of the parameters' ``.grad``."""
         lib = _lib.load()
-        flat = flatten_(self.params)
+        if getattr(self, "_flat_cache", None) is None:
+            self._flat_cache = FlatCache()
+        flat = self._flat_cache.get(self.params, flatten_)
         dev = _lib.require_device(flat)
-        missing = [p.grad is None for p in self.params]
-        if all(missing):       # torch.optim.Adam skips parameters without a gradient: nothing to do
-            return
-        if any(missing):
-            raise RuntimeError("FusedAdam updates one flat buffer: every parameter needs a gradient (torch.optim.Adam would "
-                               "skip the ones without; use it for partially frozen models)")
-        grads = chain_view([p.grad for p in self.params])
-        if grads is None:      # gradients that did not come from the fused training step: gather them (plumbing)
-            grads = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in self.params])
+        if flat_grads is not None:
+            grads = flat_grads
+            if grads.numel() != flat.numel() or grads.device != flat.device or grads.dtype != torch.float32:
+                raise RuntimeError("flat_grads does not match the parameters")
+        else:
+            missing = [p.grad is None for p in self.params]
+            if all(missing):       # torch.optim.Adam skips parameters without a gradient: nothing to do
+                return
+            if any(missing):
+                raise RuntimeError("FusedAdam updates one flat buffer: every parameter needs a gradient (torch.optim.Adam would "
+                                   "skip the ones without; use it for partially frozen models)")
+            grads = chain_view([p.grad for p in self.params])
+            if grads is None:      # gradients that did not come from the fused training step: gather them (plumbing)
+                grads = torch.cat([p.grad.reshape(-1).to(torch.float32) for p in self.params])
         self._state(flat)
         g = self.param_groups[0]
         beta1, beta2 = g['betas']
@@ -147,12 +156,12 @@ def optimization_manager(config):
     folds the EMA update of ``models/ema.py:24-42`` into the same pass."""
 
     def optimize_fn(optimizer, params, step, lr=config.optim.lr, warmup=config.optim.warmup, grad_clip=config.optim.grad_clip,
-                    ema=None):
+                    ema=None, flat_grads=None):
         if warmup > 0:
             for g in optimizer.param_groups:
                 g['lr'] = lr * np.minimum(step / warmup, 1.0)
         if isinstance(optimizer, FusedAdam):
-            optimizer.step(grad_clip=grad_clip, ema=ema)
+            optimizer.step(grad_clip=grad_clip, ema=ema, flat_grads=flat_grads)
             return
         if grad_clip >= 0:                      # a torch optimiser handed in by the caller: the reference's own lines
             torch.nn.utils.clip_grad_norm_(params, max_norm=grad_clip)
@@ -211,8 +220,20 @@ class _DsmStep(torch.autograd.Function):
         return (None, None) + tuple(outs)
 
 
+def state_tensors(model) -> list:
+    """``list(model.state_dict(keep_vars=True).values())``, remembered on the module (``state_dict()`` walks every
+    sub-module: 0.4 ms per call, twice per training step).  The tensors' identities do not change while a model lives;
+    ``load_state_dict`` copies into them."""
+    ts = getattr(model, "_state_tensors", None)
+    if ts is None:
+        ts = list(model.state_dict(keep_vars=True).values())
+        model._state_tensors = ts
+        model._state_flat_cache = FlatCache()
+    return ts
+
+
 def dsm_step(model: CATE, sde, x, t, z, mask, *, reduce_mean=True, keep: Optional[torch.Tensor] = None,
-             dropout_p: float = 0.0, need_grads: bool = True):
+             dropout_p: float = 0.0, need_grads: bool = True, out_grads: Optional[torch.Tensor] = None):
     """One call of ``dnag_cate_dsm_step``: returns ``(loss [device scalar], flat_grads or None)`` with
     ``flat_grads`` in ``state_dict()`` order.  ``t`` [B] and ``z`` [B,N,V] are the random draws of
     ``losses.py:139`` and ``:141``; ``keep`` the packed dropout masks (None: dropout off)."""
@@ -241,8 +262,8 @@ def dsm_step(model: CATE, sde, x, t, z, mask, *, reduce_mean=True, keep: Optiona
         m = m.unsqueeze(0)
     if m.shape[1:] != (N, N) or m.shape[0] not in (1, B):
         raise ValueError(f"mask has shape {tuple(m.shape)}, expected [{B}|1, {N}, {N}]")
-    params = [p for p in model.state_dict(keep_vars=True).values()]
-    flat = chain_view([p.data for p in params])          # already one flat buffer once an optimiser step has run
+    params = state_tensors(model)
+    flat = model._state_flat_cache.get(params)                 # already one flat buffer once an optimiser step has run
     if flat is None:
         flat = torch.cat([p.detach().reshape(-1) for p in params]).to(torch.float32).contiguous()
     dc = model.dims_c()
@@ -260,7 +281,9 @@ def dsm_step(model: CATE, sde, x, t, z, mask, *, reduce_mean=True, keep: Optiona
         if keep.numel() != lib.dnag_dropout_mask_bytes(C.byref(dc), B):
             raise ValueError("keep has the wrong size for this batch (see dropout_mask_layout)")
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    grads = torch.empty_like(flat) if need_grads else None
+    grads = (out_grads if out_grads is not None else torch.empty_like(flat)) if need_grads else None
+    if grads is not None and (grads.numel() != flat.numel() or grads.device != flat.device or grads.dtype != torch.float32):
+        raise ValueError("out_grads does not match the parameters")
     a = _lib.TrainArgsC()
     a.cate_dims = C.pointer(dc)
     a.params = _lib.ptr(flat); a.tables = _lib.ptr(model._tables_dev)
@@ -293,7 +316,7 @@ def get_sde_loss_fn_nas(sde, train, reduce_mean=True, continuous=True, likelihoo
     if not continuous:
         raise NotImplementedError("only continuous=True is supported (as in the reference's shipped configs)")
 
-    def loss_fn(model, batch):
+    def run(model, batch, need, out_grads=None):
         x, adj, mask = batch                                              # losses.py:137
         lib = _lib.load()
         dev = _lib.require_device(x, mask)
@@ -317,14 +340,22 @@ def get_sde_loss_fn_nas(sde, train, reduce_mean=True, continuous=True, likelihoo
                     _lib.check(lib.dnag_dropout_fill(C.byref(dc), B, p, loss_fn.seed, keep.data_ptr(), _lib.current_stream(dev)),
                                "dnag_dropout_fill")
                 loss_fn.seed += 1
+        return dsm_step(model, sde, x, t.to(dev), z.to(dev), mask, reduce_mean=reduce_mean, keep=keep, dropout_p=p,
+                        need_grads=need, out_grads=out_grads)
+
+    def loss_fn(model, batch):
         need = train and torch.is_grad_enabled()
-        loss, grads = dsm_step(model, sde, x, t.to(dev), z.to(dev), mask, reduce_mean=reduce_mean, keep=keep, dropout_p=p,
-                               need_grads=need)
+        loss, grads = run(model, batch, need)
         if not need:
             return loss
-        params = list(model.state_dict(keep_vars=True).values())
-        return _DsmStep.apply(loss, grads, *params)
+        return _DsmStep.apply(loss, grads, *state_tensors(model))
 
+    def fused(model, batch, out_grads=None):
+        """``(loss, flat gradients)`` of one training step without the autograd round trip (``loss_fn`` + ``loss.backward()``
+        hands the same buffer to the parameters' ``.grad`` through ``torch.autograd``: 1.4 ms of host time per step)."""
+        return run(model, batch, True, out_grads)
+
+    loss_fn.fused = fused
     loss_fn.draws = None
     loss_fn.dropout_keep = None
     loss_fn.seed = 0
@@ -347,16 +378,35 @@ def get_step_fn(sde, train, optimize_fn=None, reduce_mean=False, continuous=True
         model = state['model']
         if train:
             optimizer = state['optimizer']
+            if isinstance(optimizer, FusedAdam) and hasattr(state['ema'], 'flat_shadow') and hasattr(loss_fn, 'fused') \
+                    and optimizer.params and all(a is b for a, b in zip(optimizer.params, state_tensors(model))) \
+                    and len(optimizer.params) == len(state_tensors(model)):
+                # The fused path: zero_grad / loss_fn / loss.backward() / optimize_fn / ema.update of the reference's step_fn
+                # (losses.py:204-227) as two library calls on flat buffers.  The parameters' .grad are views of the step's
+                # gradient buffer, as after loss.backward() (re-attached only when something detached them).
+                gbuf = getattr(optimizer, "_grad_buf", None)
+                flat_n = sum(p.numel() for p in optimizer.params) if gbuf is None else gbuf.numel()
+                if gbuf is None or gbuf.device != optimizer.params[0].device:
+                    gbuf = torch.empty(flat_n, dtype=torch.float32, device=optimizer.params[0].device)
+                    optimizer._grad_buf = gbuf
+                    optimizer._grad_views = None
+                loss, grads = loss_fn.fused(model, batch, out_grads=gbuf)
+                views = getattr(optimizer, "_grad_views", None)
+                if views is None:
+                    views, o = [], 0
+                    for p in optimizer.params:
+                        views.append(gbuf[o:o + p.numel()].view(p.shape))
+                        o += p.numel()
+                    optimizer._grad_views = views
+                if optimizer.params[0].grad is not views[0] or optimizer.params[-1].grad is not views[-1]:
+                    for p, v in zip(optimizer.params, views):
+                        p.grad = v
+                optimize_fn(optimizer, model.parameters(), step=state['step'], ema=state['ema'], flat_grads=grads)
+                state['step'] += 1
+                return loss
             optimizer.zero_grad()
             loss = loss_fn(model, batch)
             loss.backward()
-            if isinstance(optimizer, FusedAdam) and hasattr(state['ema'], 'flat_shadow'):
-                optimize_fn(optimizer, model.parameters(), step=state['step'], ema=state['ema'])     # Adam + EMA in one pass
-                state['step'] += 1
-            else:
-                optimize_fn(optimizer, model.parameters(), step=state['step'])
-                state['step'] += 1
-                state['ema'].update(model.parameters())
         else:
             with torch.no_grad():
                 ema = state['ema']

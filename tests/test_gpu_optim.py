@@ -256,3 +256,49 @@ def test_packed_weights_follow_fused_updates_and_ema_swaps():
     model.train()
     step_fn(state, (x.to(DEV), maskB.to(DEV), maskB.to(DEV)))
     check("after a third step")
+
+
+@pytest.mark.gpu
+def test_fused_step_fn_equals_the_autograd_sequence_bit_for_bit():
+    """step_fn's fused path (flat gradients straight into FusedAdam, no torch.autograd round trip) against the reference's
+    own sequence spelled out -- zero_grad, loss_fn, loss.backward(), optimize_fn, (EMA inside) -- on a twin model with the
+    same draws and dropout seed: parameters, EMA shadow, loss and the parameters' .grad must agree bit for bit."""
+    dims = CateDims()
+    B = 24
+    sd0 = synthetic.cate_state_dict(dims, seed=5, perturb_norms=True)
+    cfg = Cfg(optim=Cfg(optimizer="Adam", lr=1e-3, beta1=0.9, eps=1e-8, weight_decay=0.0, warmup=4, grad_clip=1.0))
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    twins = []
+    for _ in range(2):
+        model = mutils.create_model(score_config(dims, DEV))
+        model.load_state_dict(sd0)
+        model.dropout_p = 0.1
+        model.train()
+        state = dict(model=model, optimizer=losses.get_optimizer(cfg, model.parameters()), step=1,
+                     ema=ema_lib.ExponentialMovingAverage(model.parameters(), decay=0.999))
+        fn = losses.get_step_fn(sde, train=True, optimize_fn=losses.optimization_manager(cfg), reduce_mean=True)
+        twins.append((state, fn))
+    (sa, fa), (sb, fb) = twins
+    optimize_fn = losses.optimization_manager(cfg)
+    rs = np.random.RandomState(11)
+    from oracle import dnag_oracle as O
+    mask = O.nb201_adj().unsqueeze(0).repeat(B, 1, 1).to(DEV)
+    for it in range(3):
+        x = torch.from_numpy(np.eye(7, dtype=np.float32)[rs.randint(0, 7, size=(B, 8))] * 2 - 1).to(DEV)
+        t = torch.from_numpy(rs.uniform(1e-3, 1, B).astype(np.float32)).to(DEV)
+        z = torch.from_numpy(rs.standard_normal((B, 8, 7)).astype(np.float32)).to(DEV)
+        fa.loss_fn.draws = (t, z)
+        loss_a = fa(sa, (x, mask, mask))                                    # fused path
+        fb.loss_fn.draws = (t, z)
+        sb["optimizer"].zero_grad()                                         # the reference's lines (losses.py:207-214)
+        loss_b = fb.loss_fn(sb["model"], (x, mask, mask))
+        loss_b.backward()
+        optimize_fn(sb["optimizer"], sb["model"].parameters(), step=sb["step"], ema=sb["ema"])
+        sb["step"] += 1
+        assert torch.equal(loss_a.detach().reshape(()), loss_b.detach().reshape(())), it
+        for pa, pb in zip(sa["model"].parameters(), sb["model"].parameters()):
+            assert torch.equal(pa.detach(), pb.detach()), it
+            assert pa.grad is not None and torch.equal(pa.grad, pb.grad), it
+        for a_, b_ in zip(sa["ema"].shadow_params, sb["ema"].shadow_params):
+            assert torch.equal(a_, b_), it
+    assert sa["step"] == sb["step"] == 4
