@@ -122,7 +122,22 @@ struct SplitF32Args {
 __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, size_t n, float *__restrict__ out) {
     __shared__ float sh[256];
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {       // 16-byte loads, four in flight
+        const v4f *x4 = reinterpret_cast<const v4f *>(x);
+        const size_t n4 = n >> 2, stride = (size_t)gridDim.x * 256;
+        size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            const v4f a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))), fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)))));
+            m = fmaxf(m, fmaxf(fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))), fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)))));
+        }
+        for (; i < n4; i += stride) {
+            const v4f a = x4[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    }
     sh[threadIdx.x] = m;
     __syncthreads();
     for (int s2 = 128; s2 > 0; s2 >>= 1) {

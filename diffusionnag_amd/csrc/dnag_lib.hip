@@ -1277,16 +1277,20 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     const int B = p->batch, N = cd.max_node, V = cd.n_vocab, d = e.d, dff = e.dff, L = e.L, F = e.F, Hd = e.Hd;
     const size_t rows = w.rows, rows_pad = w.rows_pad;
     const bool drop = p->keep != nullptr && p->dropout_p > 0.f;
-    auto cpy = [&](size_t dst, const float *src, size_t n) { return hipMemcpyAsync(P + dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st); };
+    CopySegs segs;
+    segs.count = 0;
+    auto cpy = [&](float *dst, const float *src, size_t n) { const int k = segs.count++; segs.src[k] = src; segs.dst[k] = dst; segs.n[k] = n; };
 
     // ---- 0. pack: state order -> kernel layouts (forward + transposed backward operands) -------------------
-    HIP_TRY(cpy(e.emb_w, S + sl.emb_w, (size_t)d * V));
-    HIP_TRY(cpy(e.emb_b, S + sl.emb_b, (size_t)d + 4 * d * d + 4 * d + 4 * d * d + d));      // emb_b, timeEmb1, timeEmb2
-    HIP_TRY(cpy(e.f0_w, S + sl.f0_w, (size_t)Hd * F + Hd + (size_t)Hd * Hd + Hd));             // final.linears.0, .1
-    HIP_TRY(cpy(e.f2_w, S + sl.f2_w, (size_t)V * Hd));
-    HIP_TRY(cpy(e.f2_b, S + sl.f2_b, (size_t)V));
-    HIP_TRY(cpy(e.pe, p->tables, (size_t)N * d));
-    HIP_TRY(cpy(e.freq, p->tables + (size_t)N * d, (size_t)d / 2));
+    cpy(P + e.emb_w, S + sl.emb_w, (size_t)d * V);
+    cpy(P + e.emb_b, S + sl.emb_b, (size_t)d + 4 * d * d + 4 * d + 4 * d * d + d);      // emb_b, timeEmb1, timeEmb2
+    cpy(P + e.f0_w, S + sl.f0_w, (size_t)Hd * F + Hd + (size_t)Hd * Hd + Hd);             // final.linears.0, .1
+    cpy(P + e.f2_w, S + sl.f2_w, (size_t)V * Hd);
+    cpy(P + e.f2_b, S + sl.f2_b, (size_t)V);
+    cpy(P + e.pe, p->tables, (size_t)N * d);
+    cpy(P + e.freq, p->tables + (size_t)N * d, (size_t)d / 2);
+    hipLaunchKernelGGL(copy_segs_kernel, dim3(512), dim3(256), 0, st, segs);
+    LAUNCH_CHECK();
     hipLaunchKernelGGL(train_scales_kernel, dim3(L), dim3(256), 0, st, S, sl, P, tl, drop ? 1.0f / (1.0f - p->dropout_p) : 1.0f);
     LAUNCH_CHECK();
     hipLaunchKernelGGL(train_pack_layers_kernel, dim3(32, L), dim3(256), 0, st, S, sl, P, tl);
@@ -1379,8 +1383,14 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     LAUNCH_CHECK();
     hipLaunchKernelGGL(train_unfold_layers_kernel, dim3(32, L), dim3(256), 0, st, ws + w.gsum, gl, S, sl, G, d, dff);
     LAUNCH_CHECK();
-    HIP_TRY(hipMemcpyAsync(G + sl.emb_w, ws + w.gsum + gl.emb_w, (size_t)d * V * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(G + sl.emb_b, ws + w.gsum + gl.emb_b, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, st));
+    {
+        CopySegs gs;
+        gs.count = 2;
+        gs.src[0] = ws + w.gsum + gl.emb_w; gs.dst[0] = G + sl.emb_w; gs.n[0] = (size_t)d * V;
+        gs.src[1] = ws + w.gsum + gl.emb_b; gs.dst[1] = G + sl.emb_b; gs.n[1] = (size_t)d;
+        hipLaunchKernelGGL(copy_segs_kernel, dim3(2), dim3(256), 0, st, gs);
+        LAUNCH_CHECK();
+    }
     // ---- 6. time-embedding MLP backward --------------------------------------------------------------------------------
     hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(B), dim3(256), (size_t)d * sizeof(float), st, ws + w.dtau, ws + w.save_pre, d, P + e.t2_w, ws + w.dpre);
     LAUNCH_CHECK();

@@ -372,6 +372,17 @@ __global__ __launch_bounds__(256) void tn_few_kernel(const float *__restrict__ A
         if (i < I) out[(size_t)blockIdx.z * I * J + (size_t)i * J + j] = acc[i];
 }
 
+// Up to eight contiguous runs copied by one launch (the training step's state -> kernel-layout copies were seven
+// hipMemcpyAsync calls, 4-10 us apart on the stream; a copy kernel per run costs its 4.5 us dispatch floor each).
+struct CopySegs { const float *src[8]; float *dst[8]; unsigned long long n[8]; int count; };
+__global__ __launch_bounds__(256) void copy_segs_kernel(const CopySegs c) {
+    for (int k = 0; k < c.count; ++k) {
+        const float *__restrict__ s = c.src[k];
+        float *__restrict__ d = c.dst[k];
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < c.n[k]; i += (size_t)gridDim.x * 256) d[i] = s[i];
+    }
+}
+
 // out[z][j] = sum over the z-th chunk of rows of A[r][j]
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, int lda, int rows, int chunk, int J,
                                                      float *__restrict__ out) {
