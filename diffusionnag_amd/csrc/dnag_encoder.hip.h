@@ -359,7 +359,13 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     // row `lr` of this workgroup is a real graph row (SAVE stores skip the padding)
     auto live = [&](int lr) { return lr < R && g0 + lr / N < batch; };
 
+    // co-resident workgroups swap a raised wave priority every layer (dnag_encoder8.hip.h: the arbiter serves the older
+    // wave first, and the launch lasts as long as the starved generation)
+    const int gen = (blockIdx.x >> 8) & 1;
     for (int l = 0; l < L; ++l) {
+#ifndef DNAG_ENC_NO_PRIO
+        if ((l ^ gen) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const float *LP = P + lay.layer0 + (size_t)l * lay.layer_stride;
         const float *SC = LP + lay.l_sc;          // power-of-two operand scales of this layer (dnag_common.h ENC_SC_*)
         // keep masks of this layer's sites for local row lr (DROP only; dead rows never read them)

@@ -45,8 +45,12 @@ struct v2f {
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
 __device__ __forceinline__ v2f pk_max(v2f a, v2f b) { return v2f{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
 
+// N nodes per graph: 8 (NAS-Bench-201, 8 graphs per workgroup) or 20 (MobileNetV3 / OFA: 3 graphs = 60 of the 64 rows; the four
+// spare rows stay zero, every row-wise phase carries them along and nothing reads them back)
+template <int N_>
 struct Enc8Geom {
-    static constexpr int N = 8, G = 8, R = 64, D = 64, H = 8, DK = 8, DFF = 128;
+    static constexpr int N = N_, G = 64 / N_, R = 64, RV = G * N, D = 64, H = 8, DK = 8, DFF = 128;
+    static_assert(N % 2 == 0 && G * H * (N / 2) <= 256, "one thread per (graph, head, query pair)");
     static constexpr int AS = D + 4;            // dword row stride of A16 (== 4 mod 64: conflict-free ds_read_b128)
     static constexpr int QS = 3 * D + 4;        // q|k|v rows
     static constexpr int FS = DFF + 4;          // split hidden rows (DFF values = DFF dwords)
@@ -66,13 +70,13 @@ __device__ __forceinline__ void split4(const v4f v, h4 &hi, h4 &lo) {
     }
 }
 
-template <int V>
+template <int N_, int V>
 __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restrict__ P, const CateLayout lay,
                                                           const float *__restrict__ x, const float *__restrict__ temb,
                                                           int tstride, const float *__restrict__ mask, int mstride,
                                                           float *__restrict__ concat, int batch) {
-    typedef Enc8Geom Ge;
-    constexpr int N = Ge::N, G = Ge::G, R = Ge::R, D = Ge::D, H = Ge::H, DK = Ge::DK, DFF = Ge::DFF;
+    typedef Enc8Geom<N_> Ge;
+    constexpr int N = Ge::N, G = Ge::G, R = Ge::R, RV = Ge::RV, D = Ge::D, H = Ge::H, DK = Ge::DK, DFF = Ge::DFF;
     constexpr int AS = Ge::AS, QS = Ge::QS, FS = Ge::FS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *a16 = smem;                       // [R][AS] split-pair rows, 64 values each
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     float *xin = qkv;                        // [R][V] alias
     for (int i = tid; i < R * V; i += 256) {
         const int g = i / (N * V);
-        xin[i] = (g0 + g < batch) ? x[(size_t)g0 * N * V + i] : 0.f;
+        xin[i] = (i < RV * V && g0 + g < batch) ? x[(size_t)g0 * N * V + i] : 0.f;
     }
     for (int i = tid; i < G * N * N; i += 256) {
         const int g = i / (N * N), ij = i - g * N * N;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             const int rr = i / D, c = i - rr * D;
             const int g = rr / N, n = rr - g * N;
             float val = 0.f;
-            if (g0 + g < batch) {
+            if (rr < RV && g0 + g < batch) {
                 float acc = 0.f;
 #pragma unroll
                 for (int v = 0; v < V; ++v) acc = fmaf(xin[rr * V + v], We[c * V + v], acc);
@@ -233,17 +237,27 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     // concat slice `lc` = the A16 image, copied out with full 128-byte lines: 64 rows x 2 chunks x 8 pieces of 16 bytes,
     // four pieces per thread (k-tile-blocked rows: dnag_gemm16.hip.h kblock_at).  Runs between the barrier behind P0 and
     // the one behind P1 (P2 is the next writer of A16).
+    // piece k of a thread: 16 bytes of row pc / 16.  A piece that falls on a spare row or on a graph beyond the batch is
+    // replaced by the same piece of the workgroup's first graph (always valid): the thread then reads and stores what another
+    // thread stores to the same address -- a benign duplicate, and every store stays unconditional (see stage_fetch)
+    auto piece_of = [&](int tid, int k, int &row, int &dw) {
+        const int pc = tid + 256 * k;
+        row = pc >> 4; dw = (pc & 15) * 4;
+        // (8 nodes: all 64 rows are the workgroup's own, and rows of graphs beyond the batch are pad rows of the concat,
+        // rows_pad >= 64 gridDim.x: stored as they are, finite and read by no one)
+        if constexpr (RV < R) { if (row >= RV || g0 + row / N >= batch) row = row % N; }
+    };
     auto concat_read = [&](int tid, v4f (&cc)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int pc = tid + 256 * k, row = pc >> 4, dw = (pc & 15) * 4;
+            int row, dw;
+            piece_of(tid, k, row, dw);
             cc[k] = *reinterpret_cast<const v4f *>(a16 + row * AS + dw);
         }
     };
     auto concat_write1 = [&](int tid, const v4f &c, int k, int lc) {
-        const int pc = tid + 256 * k, row = pc >> 4, dw = (pc & 15) * 4;
-        // unconditional, for the same reason as stage_fetch: rows of graphs beyond the batch are pad rows of the concat
-        // (rows_pad >= 64 * gridDim.x), finite (their x is zero) and read by no one
+        int row, dw;
+        piece_of(tid, k, row, dw);
         *reinterpret_cast<v4f *>(concat + kblock_at((size_t)g0 * N + row, (size_t)lc * D + dw, rows_pad)) = c;
     };
     auto concat_write = [&](int tid, const v4f (&cc)[4], int lc) {
@@ -359,9 +373,10 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             // behind the 36 MFMAs: the 16 pieces of W2 (P6) and, once both jobs on column tile `wave` are issued, the 8 of Wo
             // (P3) into the registers they free
             const float *W2p = LP16 + lay.l_w2, *Wop = LP16 + lay.l_wo;
-            chain64(xa, bP, c1, std::false_type{}, [&](int i) { piece(W2p, tnt, DFF, bR, i); });
+            // (20 nodes: the attention's registers cannot spare the 64 of W2 in flight; it is fetched behind P2 instead)
+            chain64(xa, bP, c1, std::false_type{}, [&](int i) { if constexpr (N <= 8) piece(W2p, tnt, DFF, bR, i); });
             E8_SUB();
-            chain64(ya, bP, c2, std::false_type{}, [&](int i) { if (i < 4) piece(W2p, tnt, DFF, bR, 12 + i); });
+            chain64(ya, bP, c2, std::false_type{}, [&](int i) { if constexpr (N <= 8) { if (i < 4) piece(W2p, tnt, DFF, bR, 12 + i); } });
             put(c1, wave, mx);
             // The concat slice of the layer before (= the A16 rows this phase reads) is read once more from LDS here, when the
             // first two jobs have released their registers, and stored behind the last four MFMAs.  Every store is
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             concat_read(tid, cc);
             const int lc = l > 0 ? l - 1 : 0;
             chain64(xa, bQ, c3, std::false_type{}, [&](int i) {
-                if (i < 8) piece(Wop, tnt, D, bP, i);
+                if (i < 8) { if constexpr (N <= 8) piece(Wop, tnt, D, bP, i); }
                 else concat_write1(tid, cc[i - 8], i - 8, lc);
             });
             put(c2, wave, mx ^ 1);
@@ -383,78 +398,182 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         // ---- P2: attention, one thread per (graph, head, query pair) ----------------------------------------
         {
             E8_IDS();
-            const int qp = tid & 3, hd = (tid >> 2) & 7, g = tid >> 5;
-            const int row0 = g * N + 2 * qp;
-            const float sa_o = SC[ENC_SC_SA_O];
-            v2f q[DK];
-            {
-                const float *qa = qkv + row0 * QS + hd * DK, *qb = qa + QS;
+            if constexpr (N <= 8) {
+                const int qp = tid & 3, hd = (tid >> 2) & 7, g = tid >> 5;
+                const int row0 = g * N + 2 * qp;
+                const float sa_o = SC[ENC_SC_SA_O];
+                v2f q[DK];
+                {
+                    const float *qa = qkv + row0 * QS + hd * DK, *qb = qa + QS;
 #pragma unroll
-                for (int e = 0; e < DK; e += 4) {
-                    const v4f a = *reinterpret_cast<const v4f *>(qa + e), b = *reinterpret_cast<const v4f *>(qb + e);
-                    q[e] = v2f{a.x, b.x}; q[e + 1] = v2f{a.y, b.y}; q[e + 2] = v2f{a.z, b.z}; q[e + 3] = v2f{a.w, b.w};
+                    for (int e = 0; e < DK; e += 4) {
+                        const v4f a = *reinterpret_cast<const v4f *>(qa + e), b = *reinterpret_cast<const v4f *>(qb + e);
+                        q[e] = v2f{a.x, b.x}; q[e + 1] = v2f{a.y, b.y}; q[e + 2] = v2f{a.z, b.z}; q[e + 3] = v2f{a.w, b.w};
+                    }
                 }
-            }
-            v2f s[N];
-            v2f mx = {-3.0e38f, -3.0e38f};
-            const float *mrow = maskb + (g * N + 2 * qp) * N;
+                v2f s[N];
+                v2f mx = {-3.0e38f, -3.0e38f};
+                const float *mrow = maskb + (g * N + 2 * qp) * N;
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const float *kp = qkv + (g * N + j) * QS + D + hd * DK;
-                v2f acc = {0.f, 0.f};
+                for (int j = 0; j < N; ++j) {
+                    const float *kp = qkv + (g * N + j) * QS + D + hd * DK;
+                    v2f acc = {0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < DK; e += 4) {
-                    const v4f k4 = *reinterpret_cast<const v4f *>(kp + e);
-                    acc = pk_fma(q[e], v2f{k4.x, k4.x}, acc);
-                    acc = pk_fma(q[e + 1], v2f{k4.y, k4.y}, acc);
-                    acc = pk_fma(q[e + 2], v2f{k4.z, k4.z}, acc);
-                    acc = pk_fma(q[e + 3], v2f{k4.w, k4.w}, acc);
+                    for (int e = 0; e < DK; e += 4) {
+                        const v4f k4 = *reinterpret_cast<const v4f *>(kp + e);
+                        acc = pk_fma(q[e], v2f{k4.x, k4.x}, acc);
+                        acc = pk_fma(q[e + 1], v2f{k4.y, k4.y}, acc);
+                        acc = pk_fma(q[e + 2], v2f{k4.z, k4.z}, acc);
+                        acc = pk_fma(q[e + 3], v2f{k4.w, k4.w}, acc);
+                    }
+                    acc = acc * (1.0f / sqrtf((float)DK));
+                    if (mrow[j] == 0.f) acc.x = -1e9f;          // transformer.py:16
+                    if (mrow[N + j] == 0.f) acc.y = -1e9f;
+                    s[j] = acc;
+                    mx = pk_max(mx, acc);
                 }
-                acc = acc * (1.0f / sqrtf((float)DK));
-                if (mrow[j] == 0.f) acc.x = -1e9f;          // transformer.py:16
-                if (mrow[N + j] == 0.f) acc.y = -1e9f;
-                s[j] = acc;
-                mx = pk_max(mx, acc);
-            }
-            v2f den = {0.f, 0.f};
+                v2f den = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                s[j] = v2f{__expf(s[j].x - mx.x), __expf(s[j].y - mx.y)};
-                den += s[j];
-            }
-            const v2f rden = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};     // v_rcp_f32, 1 ulp; den in [1, 8]
-            v2f o[DK];
-#pragma unroll
-            for (int e = 0; e < DK; ++e) o[e] = v2f{0.f, 0.f};
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                const v2f p = s[j] * rden;
-                const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK;
-#pragma unroll
-                for (int e = 0; e < DK; e += 4) {
-                    const v4f v4 = *reinterpret_cast<const v4f *>(vp + e);
-                    o[e] = pk_fma(p, v2f{v4.x, v4.x}, o[e]);
-                    o[e + 1] = pk_fma(p, v2f{v4.y, v4.y}, o[e + 1]);
-                    o[e + 2] = pk_fma(p, v2f{v4.z, v4.z}, o[e + 2]);
-                    o[e + 3] = pk_fma(p, v2f{v4.w, v4.w}, o[e + 3]);
+                for (int j = 0; j < N; ++j) {
+                    s[j] = v2f{__expf(s[j].x - mx.x), __expf(s[j].y - mx.y)};
+                    den += s[j];
                 }
-            }
-            // head hd = values 8 hd .. 8 hd + 7 of the row = split group hd: 16 B of hi, 16 B of lo
+                const v2f rden = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};     // v_rcp_f32, 1 ulp; den in [1, 8]
+                v2f o[DK];
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
-                h8 hi, lo;
+                for (int e = 0; e < DK; ++e) o[e] = v2f{0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < DK; ++e) {
-                    const float v = (w ? o[e].y : o[e].x) * sa_o;
-                    const _Float16 xh = (_Float16)v;
-                    hi[e] = xh;
-                    lo[e] = (_Float16)(v - (float)xh);
+                for (int j = 0; j < N; ++j) {
+                    const v2f p = s[j] * rden;
+                    const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK;
+#pragma unroll
+                    for (int e = 0; e < DK; e += 4) {
+                        const v4f v4 = *reinterpret_cast<const v4f *>(vp + e);
+                        o[e] = pk_fma(p, v2f{v4.x, v4.x}, o[e]);
+                        o[e + 1] = pk_fma(p, v2f{v4.y, v4.y}, o[e + 1]);
+                        o[e + 2] = pk_fma(p, v2f{v4.z, v4.z}, o[e + 2]);
+                        o[e + 3] = pk_fma(p, v2f{v4.w, v4.w}, o[e + 3]);
+                    }
                 }
-                float *dst = a16 + (row0 + w) * AS + hd * 8;
-                *reinterpret_cast<h8 *>(dst) = hi;
-                *reinterpret_cast<h8 *>(dst + 4) = lo;
+                // head hd = values 8 hd .. 8 hd + 7 of the row = split group hd: 16 B of hi, 16 B of lo
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    h8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < DK; ++e) {
+                        const float v = (w ? o[e].y : o[e].x) * sa_o;
+                        const _Float16 xh = (_Float16)v;
+                        hi[e] = xh;
+                        lo[e] = (_Float16)(v - (float)xh);
+                    }
+                    float *dst = a16 + (row0 + w) * AS + hd * 8;
+                    *reinterpret_cast<h8 *>(dst) = hi;
+                    *reinterpret_cast<h8 *>(dst + 4) = lo;
+                }
+            } else {
+                constexpr int QP = N / 2;
+                const bool act = tid < G * H * QP;             // N = 20: 240 of the 256 threads
+                const int t2 = act ? tid : 0;
+                const int qp = t2 % QP, hd = (t2 / QP) % H, g = t2 / (QP * H);
+                const int row0 = g * N + 2 * qp;
+                const float sa_o = SC[ENC_SC_SA_O];
+                v2f q[DK];
+                {
+                    const float *qa = qkv + row0 * QS + hd * DK, *qb = qa + QS;
+#pragma unroll
+                    for (int e = 0; e < DK; e += 4) {
+                        const v4f a = *reinterpret_cast<const v4f *>(qa + e), b = *reinterpret_cast<const v4f *>(qb + e);
+                        q[e] = v2f{a.x, b.x}; q[e + 1] = v2f{a.y, b.y}; q[e + 2] = v2f{a.z, b.z}; q[e + 3] = v2f{a.w, b.w};
+                    }
+                }
+                const float *mrow = maskb + (g * N + 2 * qp) * N;
+                static_assert(N % 4 == 0, "mask rows as 16-byte pieces");
+                v4f mk[2][N / 4];                    // the two queries' mask rows
+#pragma unroll
+                for (int e = 0; e < N / 4; ++e) {
+                    mk[0][e] = *reinterpret_cast<const v4f *>(mrow + 4 * e);
+                    mk[1][e] = *reinterpret_cast<const v4f *>(mrow + N + 4 * e);
+                }
+                v2f o[DK];
+#pragma unroll
+                for (int e = 0; e < DK; ++e) o[e] = v2f{0.f, 0.f};
+                auto score = [&](int j) {
+                    const float *kp = qkv + (g * N + j) * QS + D + hd * DK;
+                    v2f acc = {0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < DK; e += 4) {
+                        const v4f k4 = *reinterpret_cast<const v4f *>(kp + e);
+                        acc = pk_fma(q[e], v2f{k4.x, k4.x}, acc);
+                        acc = pk_fma(q[e + 1], v2f{k4.y, k4.y}, acc);
+                        acc = pk_fma(q[e + 2], v2f{k4.z, k4.z}, acc);
+                        acc = pk_fma(q[e + 3], v2f{k4.w, k4.w}, acc);
+                    }
+                    acc = acc * (1.0f / sqrtf((float)DK));
+                    if (mk[0][j >> 2][j & 3] == 0.f) acc.x = -1e9f;          // transformer.py:16
+                    if (mk[1][j >> 2][j & 3] == 0.f) acc.y = -1e9f;
+                    return acc;
+                };
+                auto add_v = [&](int j, v2f p) {
+                    const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK;
+#pragma unroll
+                    for (int e = 0; e < DK; e += 4) {
+                        const v4f v4 = *reinterpret_cast<const v4f *>(vp + e);
+                        o[e] = pk_fma(p, v2f{v4.x, v4.x}, o[e]);
+                        o[e + 1] = pk_fma(p, v2f{v4.y, v4.y}, o[e + 1]);
+                        o[e + 2] = pk_fma(p, v2f{v4.z, v4.z}, o[e + 2]);
+                        o[e + 3] = pk_fma(p, v2f{v4.w, v4.w}, o[e + 3]);
+                    }
+                };
+                {
+                    // 20 keys: two blocks of ten with a running maximum (40 registers of scores at once, beside the 112 of weight
+                    // prefetches in flight, spilled): o and the denominator are rescaled by exp(m_old - m_new) between the blocks
+                    // and o is divided once at the end -- a few ulp from softmax-then-product, well inside the path's tolerance
+                    constexpr int KB = N / 2;
+                    v2f mx = {-3.0e38f, -3.0e38f}, den = {0.f, 0.f};
+#pragma unroll
+                    for (int b0 = 0; b0 < N; b0 += KB) {
+                        v2f s[KB];
+                        v2f mb = mx;
+#pragma unroll
+                        for (int j = 0; j < KB; ++j) {
+                            s[j] = score(b0 + j); mb = pk_max(mb, s[j]);
+                        }
+                        const v2f sc = v2f{__expf(mx.x - mb.x), __expf(mx.y - mb.y)};      // first block: exp(-3e38 - m) = 0
+                        den = den * sc;
+#pragma unroll
+                        for (int e = 0; e < DK; ++e) o[e] = o[e] * sc;
+#pragma unroll
+                        for (int j = 0; j < KB; ++j) {
+                            const v2f p = v2f{__expf(s[j].x - mb.x), __expf(s[j].y - mb.y)};
+                            den += p;
+                            add_v(b0 + j, p);
+                        }
+                        mx = mb;
+                    }
+                    const v2f rden = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+#pragma unroll
+                    for (int e = 0; e < DK; ++e) o[e] = o[e] * rden;
+                }
+                // head hd = values 8 hd .. 8 hd + 7 of the row = split group hd: 16 B of hi, 16 B of lo
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    h8 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < DK; ++e) {
+                        const float v = (w ? o[e].y : o[e].x) * sa_o;
+                        const _Float16 xh = (_Float16)v;
+                        hi[e] = xh;
+                        lo[e] = (_Float16)(v - (float)xh);
+                    }
+                    float *dst = a16 + (row0 + w) * AS + hd * 8;
+                    if (act) {
+                        *reinterpret_cast<h8 *>(dst) = hi;
+                        *reinterpret_cast<h8 *>(dst + 4) = lo;
+                    }
+                }
             }
         }
+        if constexpr (N > 8) { fetch64(LP16 + lay.l_wo, tnt, bP); fetch128(LP16 + lay.l_w2, tnt, bR); }
         __syncthreads();
         E8_STAMP();
         // ---- P3: h += attn Wo^T + bo --------------------------------------------------------------------

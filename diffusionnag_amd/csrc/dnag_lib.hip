@@ -683,17 +683,25 @@ static int launch_encoder_t(const CateLayout &lay, const float *P, const float *
     return 0;
 }
 
+template <int N, int V>
+static int launch_encoder8(const CateLayout &lay, const float *P, const float *x, const float *temb, int tstride, const float *mask,
+                           int mstride, float *concat, int batch, hipStream_t st) {
+    typedef Enc8Geom<N> Ge;
+    if (lay.d != Ge::D || lay.dff != Ge::DFF) return fail(DNAG_E_ARG, "encoder8: d_model %d / d_ff %d", lay.d, lay.dff);
+    const size_t lds = Ge::lds_floats * sizeof(float);
+    auto kern = encoder8_kernel<N, V>;
+    static LdsAttr attr;
+    if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
+    hipLaunchKernelGGL(kern, dim3((batch + Ge::G - 1) / Ge::G), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, batch);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 static int launch_encoder(const dnag_cate_dims &c, const CateLayout &lay, const float *P, const float *x, const float *temb,
                           int tstride, const float *mask, int mstride, float *concat, float *attn0, int batch, hipStream_t st) {
-    if (is_nb201(c) && attn0 == nullptr) {       // the sampling path: dnag_encoder8.hip.h
-        typedef Enc8Geom Ge;
-        const size_t lds = Ge::lds_floats * sizeof(float);
-        auto kern = encoder8_kernel<7>;
-        static LdsAttr attr;
-        if (int rc = ensure_lds(attr, reinterpret_cast<const void *>(kern), lds)) return rc;
-        hipLaunchKernelGGL(kern, dim3((batch + Ge::G - 1) / Ge::G), dim3(256), lds, st, P, lay, x, temb, tstride, mask, mstride, concat, batch);
-        LAUNCH_CHECK();
-        return 0;
+    if (attn0 == nullptr) {       // the sampling path: dnag_encoder8.hip.h
+        if (is_nb201(c)) return launch_encoder8<8, 7>(lay, P, x, temb, tstride, mask, mstride, concat, batch, st);
+        return launch_encoder8<20, 9>(lay, P, x, temb, tstride, mask, mstride, concat, batch, st);
     }
     if (is_nb201(c)) return launch_encoder_t<8, 7, 8>(lay, P, x, temb, tstride, mask, mstride, concat, attn0, batch, st);
     return launch_encoder_t<20, 9, 3>(lay, P, x, temb, tstride, mask, mstride, concat, attn0, batch, st);
