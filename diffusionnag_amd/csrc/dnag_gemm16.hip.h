@@ -147,6 +147,33 @@ __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, 
     if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int *>(out), __float_as_uint(sh[0]));
 }
 
+// c[i] *= elu'(z) given aux[i] = elu(z): 1 for aux > 0, else aux + 1; optionally max |c| -> amax_out.  The ELU-gradient
+// GEMMs of the split kernel run as ACT_NONE + this pass: with the aux read fused into its epilogue (ACT_MUL_ELUGRAD) the
+// IN_F32 kernel spills ~150-290 registers beside its 128 accumulators and the epilogue outlasts the k loop (235 us for
+// 8192 x 1536 x 1536, against 120 us + 25 us this way).
+__global__ __launch_bounds__(256) void mul_elugrad_kernel(float *__restrict__ c, const float *__restrict__ aux, size_t n4,
+                                                          float *__restrict__ amax_out) {
+    __shared__ float sh[256];
+    float m = 0.f;
+    v4f *c4 = reinterpret_cast<v4f *>(c);
+    const v4f *a4 = reinterpret_cast<const v4f *>(aux);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        v4f v = c4[i];
+        const v4f a = a4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] *= a[e] > 0.f ? 1.0f : a[e] + 1.0f; m = fmaxf(m, fabsf(v[e])); }
+        c4[i] = v;
+    }
+    if (amax_out == nullptr) return;
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s2]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned int *>(amax_out), __float_as_uint(sh[0]));
+}
+
 // FUSE_V > 0 (final.linears.1 of the score network): the MFMA operands swap roles, so that a lane holds ONE row of
 // the batch and its registers 16 output columns, and the epilogue applies final.linears.2 (W3 [FUSE_V][Nout],
 // cate.py:55-73) to the ELU output in registers: parts[tn][row][v] = sum over this block's 256 columns of

@@ -432,7 +432,7 @@ struct WsLayout {
 // workspace of one MetaPredictorCATE evaluation (float offsets relative to its base)
 struct PcWs {
     size_t rows, rows_pad, bpad;
-    size_t beff, concat, h1, h2, flat, r1, r2, pz, dr2, dr1, dflat, dh1, dconcat, sv_h, sv_h1, sv_qkv, sv_f, total;
+    size_t beff, concat, h1, h2, flat, r1, r2, pz, dr2, dr1, dflat, dh1, dconcat, sv_h, sv_h1, sv_qkv, sv_f, amax, total;
 };
 
 static size_t up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -443,10 +443,11 @@ static PcWs predcate_ws(const PredCateLayout &y, int batch) {
     PcWs w;
     const size_t N = y.enc.N, d = y.enc.d, F = y.enc.F, Hd = y.enc.Hd, L = y.enc.L;
     w.rows = (size_t)batch * N;
-    w.rows_pad = up(w.rows, GEMM_BM);
+    w.rows_pad = up(w.rows, 256);        // the split-arithmetic GEMMs of the final MLP run 256-row tiles
     w.bpad = up((size_t)batch, GEMM_BM);
     size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += up(n, 64); return at; };
+    w.amax = take(8);         // max |W0|, |W1|, |concat|, |H1|, |dH2| (float bits): operand scales of the split GEMMs
     w.beff = take(y.hs);
     w.concat = take(w.rows_pad * F);
     w.h1 = take(w.rows_pad * Hd);
@@ -884,8 +885,27 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
         LAUNCH_CHECK();
     }
     // final MLP (cate.py:323), flatten, regeress MLP (:325-326), pred_fc (:348)
-    if (int rc = launch_gemm_t<ACT_ELU, 2>(ws + w.concat, P + e.f0_w, P + e.f0_b, ws + w.h1, nullptr, w.rows_pad, Hd, F, F, Hd, Hd, st)) return rc;
-    if (int rc = launch_gemm_t<ACT_ELU, 2>(ws + w.h1, P + e.f1_w, P + e.f1_b, ws + w.h2, nullptr, w.rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    // The two 81 920-row GEMMs of the final MLP (and its ELU-gradient GEMM below) on the split-arithmetic fp16 MFMA kernel,
+    // fp32 operands split on the fly: every operand's power-of-two scale comes from its largest magnitude, measured on
+    // the device (amax_kernel, or the producing GEMM's epilogue), as in the training step.  Nout = Hd = 256 is one tile
+    // column of that kernel; the GEMMs with 128 or 384 output columns stay on the fp32 MFMA kernel.
+    float *amax_w0 = ws + w.amax, *amax_w1 = ws + w.amax + 1, *amax_cc = ws + w.amax + 2, *amax_h1 = ws + w.amax + 3, *amax_dh2 = ws + w.amax + 4;
+    const bool split_ok = Hd % SplitGeom::BN == 0 && F % GEMM_BK == 0;
+    if (split_ok) {
+        HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 8 * sizeof(float), st));
+        if (w.rows_pad > w.rows) HIP_TRY(hipMemsetAsync(ws + w.concat + w.rows * F, 0, (w.rows_pad - w.rows) * F * sizeof(float), st));
+        hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, P + e.f0_w, (size_t)Hd * F, amax_w0);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, P + e.f1_w, (size_t)Hd * Hd, amax_w1);
+        LAUNCH_CHECK();
+        hipLaunchKernelGGL(amax_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, w.rows * (size_t)F, amax_cc);
+        LAUNCH_CHECK();
+        if (int rc = launch_gemm32<ACT_ELU, 5>(ws + w.concat, F, amax_cc, P + e.f0_w, F, amax_w0, P + e.f0_b, ws + w.h1, Hd, nullptr, w.rows_pad, Hd, F, 1, st, amax_h1)) return rc;
+        if (int rc = launch_gemm32<ACT_ELU, 5>(ws + w.h1, Hd, amax_h1, P + e.f1_w, Hd, amax_w1, P + e.f1_b, ws + w.h2, Hd, nullptr, w.rows_pad, Hd, Hd, 1, st)) return rc;
+    } else {
+        if (int rc = launch_gemm_t<ACT_ELU, 2>(ws + w.concat, P + e.f0_w, P + e.f0_b, ws + w.h1, nullptr, w.rows_pad, Hd, F, F, Hd, Hd, st)) return rc;
+        if (int rc = launch_gemm_t<ACT_ELU, 2>(ws + w.h1, P + e.f1_w, P + e.f1_b, ws + w.h2, nullptr, w.rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    }
     {
         ExitArgs a;
         memset(&a, 0, sizeof(a));
@@ -910,7 +930,13 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
         hipLaunchKernelGGL((final2_bwd_kernel<PC_N, PC_V>), dim3(grid), dim3(256), 0, st, ws + w.h2, ws + w.dflat, y.RK, P + e.f2_w, Hd, rows);
         LAUNCH_CHECK();
     }
-    if (int rc = launch_gemm_t<ACT_MUL_ELUGRAD, 2>(ws + w.h2, P + y.f1T, nullptr, ws + w.dh1, ws + w.h1, w.rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
+    if (split_ok) {      // dH1 = (dH2 W1) * elu'(H1); f1T holds W1's values: the same largest magnitude
+        hipLaunchKernelGGL(amax_kernel, dim3(1024), dim3(256), 0, st, ws + w.h2, w.rows * (size_t)Hd, amax_dh2);
+        LAUNCH_CHECK();
+        if (int rc = launch_gemm32<ACT_NONE, 5>(ws + w.h2, Hd, amax_dh2, P + y.f1T, Hd, amax_w1, nullptr, ws + w.dh1, Hd, nullptr, w.rows_pad, Hd, Hd, 1, st)) return rc;
+        hipLaunchKernelGGL(mul_elugrad_kernel, dim3(2048), dim3(256), 0, st, ws + w.dh1, ws + w.h1, w.rows_pad * (size_t)Hd / 4, (float *)nullptr);
+        LAUNCH_CHECK();
+    } else if (int rc = launch_gemm_t<ACT_MUL_ELUGRAD, 2>(ws + w.h2, P + y.f1T, nullptr, ws + w.dh1, ws + w.h1, w.rows_pad, Hd, Hd, Hd, Hd, Hd, st)) return rc;
     if (int rc = launch_gemm_t<ACT_NONE, 2>(ws + w.dh1, P + y.f0T, nullptr, ws + w.dconcat, nullptr, w.rows_pad, F, Hd, Hd, F, F, st)) return rc;
     {
         typedef PcbGeom<PC_N, PC_G, 2, 32> Ge;
@@ -1376,7 +1402,10 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
         return hipGetLastError() == hipSuccess ? 0 : fail(DNAG_E_HIP, "reduce_parts_kernel launch failed");
     };
     if (int rc = wgrad_gemm(ws + w.T1, amax_dh2, ws + w.T2, amax_h1, Hd, Hd, G + sl.f1_w)) return rc;   // dW2 = dH2^T H1
-    if (int rc = launch_gemm32<ACT_MUL_ELUGRAD, 3>(ws + w.dh2, Hd, amax_dh2, P + tl.f1T, Hd, amax_w1, nullptr, ws + w.dh1, Hd, ws + w.h1, rows_pad, Hd, Hd, 1, st, amax_dh1)) return rc;
+    // dH1 = (dH2 W1) * elu'(H1): the product, then the factor in a pass of its own (dnag_gemm16.hip.h mul_elugrad_kernel)
+    if (int rc = launch_gemm32<ACT_NONE, 3>(ws + w.dh2, Hd, amax_dh2, P + tl.f1T, Hd, amax_w1, nullptr, ws + w.dh1, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
+    hipLaunchKernelGGL(mul_elugrad_kernel, dim3(2048), dim3(256), 0, st, ws + w.dh1, ws + w.h1, rows_pad * (size_t)Hd / 4, amax_dh1);
+    LAUNCH_CHECK();
     if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, st)) return rc;
     if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
     if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, st)) return rc;
