@@ -70,12 +70,18 @@ __device__ __forceinline__ void split4(const v4f v, h4 &hi, h4 &lo) {
     }
 }
 
-template <int N_, int V>
+// MODE 0: sampling path (concat = k-tile-blocked split-pair LayerNorm image).  MODE 1 / 2: the training step's forward
+// (dnag_cate_dsm_step): the activations the backward pass needs are written to `sv` (EncSave, dnag_encoder.hip.h), the
+// concat is plain fp32 rows [row][F] WITH the output norm's affine (the training head keeps the unfolded weights), and
+// MODE 2 applies the dropout keep masks `dm` at the reference's five sites (cate.py:147, transformer.py:19, :54, :80, :108).
+template <int N_, int V, int MODE = 0>
 __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restrict__ P, const CateLayout lay,
                                                           const float *__restrict__ x, const float *__restrict__ temb,
                                                           int tstride, const float *__restrict__ mask, int mstride,
-                                                          float *__restrict__ concat, int batch) {
+                                                          float *__restrict__ concat, int batch, const EncSave sv,
+                                                          const DropMasks dm) {
     typedef Enc8Geom<N_> Ge;
+    constexpr bool SAVE = MODE >= 1, DROP = MODE == 2;
     constexpr int N = Ge::N, G = Ge::G, R = Ge::R, RV = Ge::RV, D = Ge::D, H = Ge::H, DK = Ge::DK, DFF = Ge::DFF;
     constexpr int AS = Ge::AS, QS = Ge::QS, FS = Ge::FS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -95,6 +101,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     const int r = lane & 31, h = lane >> 5;
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
+    auto live = [&](int row) { return row < RV && g0 + row / N < batch; };     // a real graph row of this workgroup
     const size_t rows_pad = ((size_t)batch * N + 255) / 256 * 256;      // the concat is k-tile blocked (dnag_gemm16.hip.h kblock_at)
     const float *P16 = P + lay.delta16;      // fp16 hi/lo fragment copy of the layer matrices
 
@@ -165,10 +172,12 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
 #pragma unroll
                 for (int v = 0; v < V; ++v) acc = fmaf(xin[rr * V + v], We[c * V + v], acc);
                 val = (acc + be[c]) * 8.0f;
+                if constexpr (DROP) val = drop_apply(val, dm.keep[((size_t)g0 * N + rr) * D + c], dm.keep_prob);   // cate.py:147
                 val = val + pe[n * D + c];
                 val = val + temb[(size_t)(tstride ? g0 + g : 0) * D + c];
             }
             emb[rr * AS + c] = val;
+            if constexpr (SAVE) if (live(rr)) sv.h[((size_t)g0 * N + rr) * D + c] = val;
         }
     }
     __syncthreads();
@@ -215,10 +224,24 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     // LN(h) * 16 of the wave's registers as split-pair quads into A16.  These rows are both the next layer's QKV operand
     // and -- the affine of the output norm being folded into final.linears.0 (CateLayout::f0_s) -- the concat slice of
     // the layer that just ended, which concat_out copies to HBM.
-    auto norm_write = [&](int r, int h) {
+    auto norm_write = [&](int r, int h, int lc) {
         float mean, rstd;
         stats_get(r, mean, rstd);
         const int row = tmt * 32 + r;
+        if constexpr (SAVE) {            // concat slice lc (>= 0): LN(h) gamma + beta of layer lc's output norm, fp32 rows
+            if (lc >= 0) {
+                const float *og = P + lay.layer0 + (size_t)lc * lay.layer_stride + lay.l_ong, *ob = P + lay.layer0 + (size_t)lc * lay.layer_stride + lay.l_onb;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int c0 = tnt * 32 + 8 * gq + 4 * h;
+                    const v4f g4 = *reinterpret_cast<const v4f *>(og + c0), b4 = *reinterpret_cast<const v4f *>(ob + c0);
+                    v4f o4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o4[e] = (hacc[4 * gq + e] - mean) * rstd * g4[e] + b4[e];
+                    if (live(row)) *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + row) * lay.F + (size_t)lc * D + c0) = o4;
+                }
+            }
+        }
         rstd *= 16.0f;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -339,17 +362,22 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         {
             E8_IDS();
             if (l < L) stage_put(tid);
-            norm_write(r, h);
+            norm_write(r, h, l - 1);
         }
         if (l == L) {
             __syncthreads();
-            v4f cc[4];
-            concat_read(tid, cc);
-            concat_write(tid, cc, L - 1);
+            if constexpr (!SAVE) {
+                v4f cc[4];
+                concat_read(tid, cc);
+                concat_write(tid, cc, L - 1);
+            }
             break;
         }
         const float *LP16 = P16 + lay.layer0 + (size_t)l * lay.layer_stride;
         const float *SC = scl;
+        // keep masks of this layer's sites, row 0 of the workgroup (DROP only)
+        const uint8_t *KL = nullptr;
+        if constexpr (DROP) KL = dm.keep + dm.rows * D + ((size_t)l * dm.rows + (size_t)g0 * N) * dm.per_layer;
         __syncthreads();
         E8_STAMP();
         // ---- P1: q|k|v (and the concat slice of the layer before: the rows P1 reads) -----------------------
@@ -366,7 +394,12 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 const int col = nt * 32 + r;
                 const float bv = bias[col];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) qkv[(mt * 32 + acc_row(i, h)) * QS + col] = acc[i] * inv + bv;
+                for (int i = 0; i < 16; ++i) {
+                    const int lr = mt * 32 + acc_row(i, h);
+                    const float v = acc[i] * inv + bv;
+                    qkv[lr * QS + col] = v;
+                    if constexpr (SAVE) if (live(lr)) sv.qkv[((size_t)l * sv.rows + (size_t)g0 * N + lr) * (3 * D) + col] = v;
+                }
             };
             f32x16 c1 = zero16, c2 = zero16, c3 = zero16;
             E8_SUB();
@@ -383,11 +416,11 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             // unconditional: layer 0 writes its (meaningless) image into slice 0, which the same threads overwrite with
             // the real slice one layer later (same wave, same addresses: in order).
             v4f cc[4];
-            concat_read(tid, cc);
+            if constexpr (!SAVE) concat_read(tid, cc);
             const int lc = l > 0 ? l - 1 : 0;
             chain64(xa, bQ, c3, std::false_type{}, [&](int i) {
                 if (i < 8) { if constexpr (N <= 8) piece(Wop, tnt, D, bP, i); }
-                else concat_write1(tid, cc[i - 8], i - 8, lc);
+                else if constexpr (!SAVE) concat_write1(tid, cc[i - 8], i - 8, lc);
             });
             put(c2, wave, mx ^ 1);
             put(c3, qx, mx);
@@ -444,7 +477,13 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 for (int e = 0; e < DK; ++e) o[e] = v2f{0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const v2f p = s[j] * rden;
+                    v2f p = s[j] * rden;
+                    if constexpr (DROP) {            // transformer.py:19
+                        if (g0 + g < batch) {
+                            p.x = drop_apply(p.x, KL[(size_t)row0 * dm.per_layer + hd * N + j], dm.keep_prob);
+                            p.y = drop_apply(p.y, KL[(size_t)(row0 + 1) * dm.per_layer + hd * N + j], dm.keep_prob);
+                        }
+                    }
                     const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK;
 #pragma unroll
                     for (int e = 0; e < DK; e += 4) {
@@ -591,9 +630,20 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             E8_SUB();
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const v4f b4 = *reinterpret_cast<const v4f *>(bst + 3 * D + tnt * 32 + 8 * gq + 4 * h);
+                const int c0 = tnt * 32 + 8 * gq + 4 * h;
+                const v4f b4 = *reinterpret_cast<const v4f *>(bst + 3 * D + c0);
+                const int lr = tmt * 32 + r;
+                uint32_t kb = 0x01010101u;
+                if constexpr (DROP) if (live(lr)) kb = *reinterpret_cast<const uint32_t *>(KL + (size_t)lr * dm.per_layer + H * N + c0);   // transformer.py:80
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hacc[4 * gq + e] = (acc[4 * gq + e] * inv + b4[e]) + hacc[4 * gq + e];
+                for (int e = 0; e < 4; ++e) {
+                    float yv = acc[4 * gq + e] * inv + b4[e];
+                    if constexpr (DROP) yv = drop_apply(yv, (uint8_t)(kb >> (8 * e)), dm.keep_prob);
+                    hacc[4 * gq + e] = yv + hacc[4 * gq + e];
+                }
+                if constexpr (SAVE) if (live(lr))
+                    *reinterpret_cast<v4f *>(sv.h1 + ((size_t)l * sv.rows + (size_t)g0 * N + lr) * D + c0) =
+                        v4f{hacc[4 * gq], hacc[4 * gq + 1], hacc[4 * gq + 2], hacc[4 * gq + 3]};
             }
             stats_put(r, h);
             E8_SUB();
@@ -603,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
         // ---- P4: A16 = LN2(h), from the registers ------------------------------------------------------------
         {
             E8_IDS();
-            norm_write(r, h);
+            norm_write(r, h, -1);
         }
         __syncthreads();
         E8_STAMP();
@@ -626,8 +676,18 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
                     v4f f;
+                    const int lr = mt * 32 + r, c0 = nt * 32 + 8 * gq + 4 * h;
+                    uint32_t kb = 0x01010101u;
+                    if constexpr (DROP) if (live(lr)) kb = *reinterpret_cast<const uint32_t *>(KL + (size_t)lr * dm.per_layer + H * N + D + c0);   // transformer.py:54
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) f[e] = fmaxf(acc[4 * gq + e] * inv + bias4[gq][e], 0.f) * sa_f2;
+                    for (int e = 0; e < 4; ++e) {
+                        float fv = fmaxf(acc[4 * gq + e] * inv + bias4[gq][e], 0.f);
+                        if constexpr (DROP) fv = drop_apply(fv, (uint8_t)(kb >> (8 * e)), dm.keep_prob);
+                        f[e] = fv;
+                    }
+                    if constexpr (SAVE) if (live(lr)) *reinterpret_cast<v4f *>(sv.f + ((size_t)l * sv.rows + (size_t)g0 * N + lr) * DFF + c0) = f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) f[e] *= sa_f2;
                     h4 hi, lo;
                     split4(f, hi, lo);
                     _Float16 *dst = hrow + (nt * 4 + gq) * 16 + 4 * h;
@@ -692,9 +752,20 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             mm(6, acc); mm(7, acc);
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const v4f b4 = *reinterpret_cast<const v4f *>(bst + 4 * D + DFF + tnt * 32 + 8 * gq + 4 * h);
+                const int c0 = tnt * 32 + 8 * gq + 4 * h;
+                const v4f b4 = *reinterpret_cast<const v4f *>(bst + 4 * D + DFF + c0);
+                const int lr = tmt * 32 + r;
+                uint32_t kb = 0x01010101u;
+                if constexpr (DROP) if (live(lr)) kb = *reinterpret_cast<const uint32_t *>(KL + (size_t)lr * dm.per_layer + H * N + D + DFF + c0);   // transformer.py:108
 #pragma unroll
-                for (int e = 0; e < 4; ++e) hacc[4 * gq + e] = (acc[4 * gq + e] * inv + b4[e]) + hacc[4 * gq + e];
+                for (int e = 0; e < 4; ++e) {
+                    float yv = acc[4 * gq + e] * inv + b4[e];
+                    if constexpr (DROP) yv = drop_apply(yv, (uint8_t)(kb >> (8 * e)), dm.keep_prob);
+                    hacc[4 * gq + e] = yv + hacc[4 * gq + e];
+                }
+                if constexpr (SAVE) if (live(lr))
+                    *reinterpret_cast<v4f *>(sv.h + ((size_t)(l + 1) * sv.rows + (size_t)g0 * N + lr) * D + c0) =
+                        v4f{hacc[4 * gq], hacc[4 * gq + 1], hacc[4 * gq + 2], hacc[4 * gq + 3]};
             }
             stats_put(r, h);
             E8_SUB();

@@ -290,23 +290,25 @@ __global__ __launch_bounds__(256) void train_pack_layers_kernel(const float *__r
             double acc = SL[srcb + r];
             for (size_t k = 0; k < d; ++k) acc += (double)SL[srcw + r * d + k] * (double)SL[sl.s_ln1b + k];
             LF[tl.enc.l_bqkv + j] = (float)acc;
+            LF[tl.enc.l_vec + j] = (float)acc;          // l_vec: the contiguous copy encoder8_kernel stages (bqkv' | bo | b1' | b2 | on_g | on_b)
             continue;
         }
         j -= 3 * d;
-        if (j < d) { LF[tl.enc.l_bo + j] = SL[sl.s_bo + j]; continue; }
+        if (j < d) { LF[tl.enc.l_bo + j] = SL[sl.s_bo + j]; LF[tl.enc.l_vec + 3 * d + j] = SL[sl.s_bo + j]; continue; }
         j -= d;
         if (j < dff) {
             double acc = SL[sl.s_b1 + j];
             for (size_t k = 0; k < d; ++k) acc += (double)SL[sl.s_w1 + j * d + k] * (double)SL[sl.s_ln2b + k];
             LF[tl.enc.l_b1 + j] = (float)acc;
+            LF[tl.enc.l_vec + 4 * d + j] = (float)acc;
             continue;
         }
         j -= dff;
-        if (j < d) { LF[tl.enc.l_b2 + j] = SL[sl.s_b2 + j]; continue; }
+        if (j < d) { LF[tl.enc.l_b2 + j] = SL[sl.s_b2 + j]; LF[tl.enc.l_vec + 4 * d + dff + j] = SL[sl.s_b2 + j]; continue; }
         j -= d;
-        if (j < d) { LF[tl.enc.l_ong + j] = S[sl.norms0 + (size_t)l * 2 * d + j]; continue; }
+        if (j < d) { const float v = S[sl.norms0 + (size_t)l * 2 * d + j]; LF[tl.enc.l_ong + j] = v; LF[tl.enc.l_vec + 5 * d + dff + j] = v; continue; }
         j -= d;
-        LF[tl.enc.l_onb + j] = S[sl.norms0 + (size_t)l * 2 * d + d + j];
+        { const float v = S[sl.norms0 + (size_t)l * 2 * d + d + j]; LF[tl.enc.l_onb + j] = v; LF[tl.enc.l_vec + 6 * d + dff + j] = v; }
     }
 }
 
