@@ -1370,7 +1370,10 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     LAUNCH_CHECK();
     if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.concat, F, amax_cc, P + e.f0_w, F, amax_w0, P + e.f0_b, ws + w.h1, Hd, nullptr, rows_pad, Hd, F, 1, st, amax_h1)) return rc;
     if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.h1, Hd, amax_h1, P + e.f1_w, Hd, amax_w1, P + e.f1_b, ws + w.h2, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
-    {
+    if (V == 7 && Hd % 4 == 0) {       // out = H2 W3^T + b3, one wave per row
+        hipLaunchKernelGGL((rowdot_kernel<7>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, ws + w.h2, P + e.f2_w, P + e.f2_b, Hd, rows, ws + w.out);
+        LAUNCH_CHECK();
+    } else {
         ExitArgs a;
         memset(&a, 0, sizeof(a));
         a.mode = EXIT_FORWARD; a.batch = B; a.out = ws + w.out;

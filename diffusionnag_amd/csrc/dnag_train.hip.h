@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void tn_few_kernel(const float *__restrict__ A
     float acc[IMAX];
 #pragma unroll
     for (int i = 0; i < IMAX; ++i) acc[i] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int r = r0; r < r1; ++r) {
         const float b = Bm[(size_t)r * ldb + j];
 #pragma unroll
@@ -372,6 +372,37 @@ __global__ __launch_bounds__(256) void tn_few_kernel(const float *__restrict__ A
 #pragma unroll
     for (int i = 0; i < IMAX; ++i)
         if (i < I) out[(size_t)blockIdx.z * I * J + (size_t)i * J + j] = acc[i];
+}
+
+// out[r][v] = sum_k H[r][k] W[v][k] + b[v] for V <= 8 output columns: one wave per row, lanes stride over k with 16-byte
+// loads, butterfly reduction in a fixed order (the training step's final.linears.2 forward: head_out_kernel's k-loop path
+// has 64 rows per block = 128 blocks at B = 1024 and took 56 us for 50 MB).
+template <int V>
+__global__ __launch_bounds__(256) void rowdot_kernel(const float *__restrict__ H, const float *__restrict__ W, const float *__restrict__ b,
+                                                     int K, size_t rows, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float acc[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = 0.f;
+    const v4f *h4 = reinterpret_cast<const v4f *>(H + r * K);
+    for (int k4 = lane; k4 < K / 4; k4 += 64) {
+        const v4f x = h4[k4];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const v4f w = reinterpret_cast<const v4f *>(W + (size_t)v * K)[k4];
+            acc[v] = fmaf(x.x, w.x, acc[v]); acc[v] = fmaf(x.y, w.y, acc[v]);
+            acc[v] = fmaf(x.z, w.z, acc[v]); acc[v] = fmaf(x.w, w.w, acc[v]);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        float a = acc[v];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == v) out[r * V + v] = a + b[v];
+    }
 }
 
 // Up to eight contiguous runs copied by one launch (the training step's state -> kernel-layout copies were seven
@@ -392,7 +423,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A
     if (j >= J) return;
     const int r0 = blockIdx.z * chunk, r1 = (r0 + chunk < rows) ? r0 + chunk : rows;
     float acc = 0.f;
-    for (int r = r0; r < r1; ++r) acc += A[(size_t)r * lda + j];
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {            // eight rows requested together, added in row order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = A[(size_t)(r + k) * lda + j];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += v[k];
+    }
+    for (; r < r1; ++r) acc += A[(size_t)r * lda + j];
     out[(size_t)blockIdx.z * J + j] = acc;
 }
 
