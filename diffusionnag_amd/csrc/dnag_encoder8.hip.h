@@ -1,8 +1,9 @@
-// Sampling-path encoder of the CATE score network for 8-node graphs (NAS-Bench-201): the same mathematics as
-// encoder_kernel<8, 7, 8, 8, 128, true, false, false, true, true> (dnag_encoder.hip.h, which stays the kernel of the
-// training step, of the OFA shape and of the attention-probability output), organised around what that kernel's
-// per-phase cycle stamps showed: it is bound by vector-ALU issue, most of it the LayerNorm and
-// the fp16 hi/lo split of the A operand, which every 32x32 tile job repeated (12 QKV jobs for 2 row tiles).
+// Encoder of the CATE score network, 64 rows (8 graphs of 8 nodes, NAS-Bench-201, or 3 graphs of 20, MobileNetV3 / OFA) per
+// workgroup: the sampling path (MODE 0) and the training step's forward (MODE 1 / 2: saved activations, dropout).  The same
+// mathematics as encoder_kernel<...> (dnag_encoder.hip.h, which stays the kernel of the attention-probability output and
+// of the OFA surrogate's own encoder), organised around what that kernel's per-phase cycle stamps showed: it was bound by
+// vector-ALU issue, most of it the LayerNorm and the fp16 hi/lo split of the A operand, which every 32x32 tile job
+// repeated (12 QKV jobs for 2 row tiles).
 //
 // Here every activation that feeds a linear is normalised / scaled / split ONCE, by the phase that produces it, into an
 // LDS image of split-pair rows (dnag_gemm16.hip.h: per 8 values 16 B of fp16 hi, 16 B of lo), so a tile job is two
@@ -10,8 +11,8 @@
 //   P0  finish the row statistics of h (see below): concat slice of the previous layer (output norm, transformer.py:177)
 //       and LN1(h) -> A16, from the wave's registers
 //   P1  q|k|v = A16 Wqkv'^T + b            (3 tile jobs per wave)                    -> qkv fp32 [64][192]
-//   P2  attention: one thread per (graph, head, query pair): K and V rows are read once for two queries and the
-//       two dot products / two output rows ride on packed fp32 FMAs                   -> A16 (scale sa_o)
+//   P2  attention: one thread per (graph, head, query pair): K and V rows are read once for two queries (scalar pairs that
+//       the compiler packs into v_pk_fma_f32 where it can); 20 keys: two blocks with a running maximum   -> A16 (scale sa_o)
 //   P3  h += A16 Wo^T + bo                 (the wave's tile of h lives in registers)
 //   P4  LN2(h) -> A16, from the wave's registers
 //   P5  hidden = relu(A16 W1'^T + b1'), MFMA operands swapped so that a lane owns one batch row and writes its 16
@@ -23,6 +24,9 @@
 // lane's 16 values, merged with the other lane half (v_permlane32_swap) and -- through 8 bytes per row and tile in LDS,
 // across the barrier that separates the phases anyway -- with the wave that holds the row's other 32 columns (Chan's
 // pairwise update: no cancellation), then the wave normalises its own registers and writes its part of the split image.
+// Weight fragments travel global -> registers one to two phases ahead, one 1 KB piece behind each MFMA of the accumulation
+// chains; every global operation of the layer loop is unconditional (exact s_waitcnt vmcnt counts); lane ids are re-derived
+// per phase (E8_IDS); the two workgroups of a CU swap a raised wave priority every layer (profiles/r03d_pmc_sq_and_stamps.md).
 // Restates (reference NAS-Bench-201/): models/cate.py:145-160, models/transformer.py:12-20, :23-42, :69-80, :97-108,
 // :127-136, :166-179, models/cate.py:83-86.
 #pragma once
