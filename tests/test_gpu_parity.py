@@ -828,8 +828,9 @@ def test_vesde_philox_prior_scale_and_score_fn_wrapper():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,scale", [(4096, 1.0), (13, 1.0), (512, 30.0)])
-def test_sampling_encoder_matches_generic_encoder(B, scale):
+@pytest.mark.parametrize("shape,B,scale", [("nb201", 4096, 1.0), ("nb201", 13, 1.0), ("nb201", 512, 30.0),
+                                           ("ofa", 1, 1.0), ("ofa", 2, 1.0), ("ofa", 13, 1.0), ("ofa", 700, 1.0), ("ofa", 4096, 1.0), ("ofa", 300, 30.0)])
+def test_sampling_encoder_matches_generic_encoder(shape, B, scale):
     """encoder8_kernel (v_rsq_f32 / v_rcp_f32 / __expf, statistics merged pairwise in registers) against the generic
     encoder_kernel on the same inputs: the kernels' own distance, without any trajectory amplification (the
     trajectory tolerances alone do not say how much of their slack is kernel error).  Measured 4e-7 (concat) / 6e-7 (head
@@ -838,11 +839,14 @@ def test_sampling_encoder_matches_generic_encoder(B, scale):
     from diffusionnag_amd.specs import CateDims
     from tests.helpers import score_config
     dev = "cuda:0"
-    m = mutils.create_model(score_config(CateDims(), dev)); m.load_state_dict(synthetic.cate_state_dict(CateDims(), seed=0)); m.eval()
+    # OFA: 3 graphs of 20 nodes per workgroup, batches that do not fill the last workgroup (its concat pieces are stored as
+    # duplicates of valid ones) and 20 keys in two softmax blocks
+    dims = CateDims() if shape == "nb201" else CateDims(max_node=20, n_vocab=9, stagewise_pos=True)
+    m = mutils.create_model(score_config(dims, dev)); m.load_state_dict(synthetic.cate_state_dict(dims, seed=0)); m.eval()
     g = torch.Generator(device="cpu").manual_seed(5)
-    X = (torch.randn(B, 8, 7, generator=g) * scale).to(dev)
+    X = (torch.randn(B, dims.max_node, dims.n_vocab, generator=g) * scale).to(dev)
     t = torch.full((1,), 700.0, device=dev)
-    mk = utils.aug_mask(utils.nb201_adj()).to(dev)
+    mk = (utils.aug_mask(utils.nb201_adj()) if shape == "nb201" else utils.ofa_adj().unsqueeze(0)).to(dev)
     ref_out, ref_c, _ = m(X, t, mk, return_concat=True, return_attn0=True)      # attention probabilities: the generic kernel
     out, c, _ = m(X, t, mk, return_concat=True)                                  # the sampling path: encoder8_kernel
     ec = float((c - ref_c).abs().max() / ref_c.abs().max())
