@@ -166,16 +166,22 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     __syncthreads();
     // ---- embedding: (x We^T + be) * sqrt(d) + PE + temb   (transformer.py:230, cate.py:149-159) ----
     {
-        const float *We = P + lay.emb_w, *be = P + lay.emb_b, *pe = P + lay.pe;
-        for (int i = tid; i < R * D; i += 256) {
-            const int rr = i / D, c = i - rr * D;
+        // 256 threads over D = 64 columns: a thread keeps its column for every row it
+        // embeds, so the column's weights are read once
+        const float *pe = P + lay.pe;
+        const int c = tid & (D - 1);
+        float wec[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) wec[v] = P[lay.emb_w + c * V + v];
+        const float bec = P[lay.emb_b + c];
+        for (int rr = tid / D; rr < R; rr += 256 / D) {
             const int g = rr / N, n = rr - g * N;
             float val = 0.f;
             if (rr < RV && g0 + g < batch) {
                 float acc = 0.f;
 #pragma unroll
-                for (int v = 0; v < V; ++v) acc = fmaf(xin[rr * V + v], We[c * V + v], acc);
-                val = (acc + be[c]) * 8.0f;
+                for (int v = 0; v < V; ++v) acc = fmaf(xin[rr * V + v], wec[v], acc);
+                val = (acc + bec) * 8.0f;
                 if constexpr (DROP) val = drop_apply(val, dm.keep[((size_t)g0 * N + rr) * D + c], dm.keep_prob);   // cate.py:147
                 val = val + pe[n * D + c];
                 val = val + temb[(size_t)(tstride ? g0 + g : 0) * D + c];
@@ -450,7 +456,16 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 }
                 v2f s[N];
                 v2f mx = {-3.0e38f, -3.0e38f};
-                const float *mrow = maskb + (g * N + 2 * qp) * N;
+                static_assert(N % 4 == 0, "mask rows as 16-byte pieces");
+                float mk[2 * N];                     // the two queries' mask rows, adjacent in LDS
+                {
+                    const float *mrow = maskb + (g * N + 2 * qp) * N;
+#pragma unroll
+                    for (int e = 0; e < 2 * N; e += 4) {
+                        const v4f m4 = *reinterpret_cast<const v4f *>(mrow + e);
+                        mk[e] = m4.x; mk[e + 1] = m4.y; mk[e + 2] = m4.z; mk[e + 3] = m4.w;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float *kp = qkv + (g * N + j) * QS + D + hd * DK;
@@ -464,8 +479,8 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                         acc = pk_fma(q[e + 3], v2f{k4.w, k4.w}, acc);
                     }
                     acc = acc * (1.0f / sqrtf((float)DK));
-                    if (mrow[j] == 0.f) acc.x = -1e9f;          // transformer.py:16
-                    if (mrow[N + j] == 0.f) acc.y = -1e9f;
+                    if (mk[j] == 0.f) acc.x = -1e9f;            // transformer.py:16
+                    if (mk[N + j] == 0.f) acc.y = -1e9f;
                     s[j] = acc;
                     mx = pk_max(mx, acc);
                 }
