@@ -983,6 +983,40 @@ __global__ void put_labels_kernel(float *__restrict__ dst, const LabelChunk c, i
     if ((int)threadIdx.x < n) dst[threadIdx.x] = c.v[threadIdx.x];
 }
 
+// The surrogate's gradient and the score network's forward of one evaluation read the same x and meet only in the exit
+// kernel, so the surrogate runs on a second stream of the library's own (one per device, created on first use, kept until
+// the process ends), forked from and joined to the caller's stream by events: its workgroups fill the CUs the other
+// kernels' last rounds leave idle.  Results do not change (same kernels, disjoint workspace regions).  The first guided
+// call on a device creates the stream and its two events: make it outside a stream capture.
+// DNAG_OVERLAP=0 in the environment keeps everything on the caller's stream.
+struct SideStream { hipStream_t st; hipEvent_t fork, join; bool ok; std::mutex use; };
+static SideStream g_side[64];
+static std::mutex g_side_mu;
+static int side_for_current_device(SideStream **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(DNAG_E_ARG, "device %d", dev);
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideStream &s = g_side[dev];
+    if (!s.ok) {
+        // highest priority: the surrogate's many short, under-filled kernels are dispatched as they become ready and the
+        // score network's large ones take what is left (OFA, B = 4096, same box: 657 samples/s on one stream, 683 with
+        // this stream at the lowest priority, 720 at the default, 734 at the highest)
+        int lo = 0, hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIP_TRY(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+        s.ok = true;
+    }
+    *out = &s;
+    return 0;
+}
+static bool overlap_enabled() {
+    const char *e = getenv("DNAG_OVERLAP");      // read per call: a test compares both settings in one process
+    return !(e && e[0] == '0');
+}
+
 extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     if (!p) return fail(DNAG_E_ARG, "args is NULL");
     if (int rc = check_cate(p->cate_dims)) return rc;
@@ -1070,6 +1104,12 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
     LAUNCH_CHECK();
 
     auto rec_at = [&](float *base, int i) -> float * { return base ? base + (size_t)i * nelem : nullptr; };
+    SideStream *side = nullptr;
+    if (guided && overlap_enabled()) if (int rc = side_for_current_device(&side)) return rc;
+    // one trajectory at a time enqueues on a device's second stream: a wait takes the event's record as of the call, so
+    // two host threads interleaving their records of the same pair of events would wait for each other's work
+    std::unique_lock<std::mutex> side_lock;
+    if (side) side_lock = std::unique_lock<std::mutex>(side->use);
 
     for (int i = 0; i < S; ++i) {
         const float *row = p->sched + (size_t)i * DNAG_SCHED_COLS;
@@ -1080,13 +1120,17 @@ extern "C" int dnag_pc_sample(const dnag_pc_args *p) {
             const int ci = i * CS + sub;          // index of this corrector update in the tape / the records
             const bool guide_now = guided && (p->guide_steps == nullptr || p->guide_steps[i] != 0);
             if (guide_now) {
+                hipStream_t sg = st;
+                if (side) { HIP_TRY(hipEventRecord(side->fork, st)); HIP_TRY(hipStreamWaitEvent(side->st, side->fork, 0)); sg = side->st; }
                 if (guided_pc) {
-                    if (int rc = run_predcate(pclay, p->predcate_packed, x, ws + w.temb_p + (size_t)i * pclay.enc.d, 0, p->mask, 0, nullptr, cgrad, B, ws + w.pc, pcw, st)) return rc;
-                } else if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, ws + w.c0, nullptr, cgrad, B, st)) return rc;
+                    if (int rc = run_predcate(pclay, p->predcate_packed, x, ws + w.temb_p + (size_t)i * pclay.enc.d, 0, p->mask, 0, nullptr, cgrad, B, ws + w.pc, pcw, sg)) return rc;
+                } else if (int rc = launch_predictor(play, p->pred_packed, x, ws + w.temb_p + (size_t)i * play.g, 0, p->mask, 0, ws + w.c0, nullptr, cgrad, B, sg)) return rc;
                 float *rc_ = corr ? rec_at(p->rec_cgrad_c, ci) : rec_at(p->rec_cgrad_p, i);
-                if (rc_) HIP_TRY(hipMemcpyAsync(rc_, cgrad, nelem * sizeof(float), hipMemcpyDeviceToDevice, st));
+                if (rc_) HIP_TRY(hipMemcpyAsync(rc_, cgrad, nelem * sizeof(float), hipMemcpyDeviceToDevice, sg));
+                if (side) HIP_TRY(hipEventRecord(side->join, side->st));
             }
             if (int rc = run_score_body(cd, lay, p->cate_packed, x, ws + w.temb_s + (size_t)i * lay.d, 0, p->mask, 0, ws, w, nullptr, B, st)) return rc;
+            if (guide_now && side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
             ExitArgs a;
             memset(&a, 0, sizeof(a));
             a.mode = corr ? EXIT_CORRECTOR : EXIT_PREDICTOR;

@@ -645,6 +645,25 @@ def test_pc_guided_ofa_full_trajectory_contractive():
     assert np.array_equal(q, (g["final"] >= 0.5).astype(np.float32)), "discretised architectures differ"
 
 
+@pytest.mark.parametrize("shape", ["nb201", "ofa"])
+def test_second_stream_changes_no_bit(shape, monkeypatch):
+    """The surrogate's gradient runs on the library's second stream beside the score network (dnag_lib.hip SideStream);
+    with DNAG_OVERLAP=0 everything stays on the caller's stream.  Same kernels, same operands: every record equal."""
+    g = golden("pc_guided_nb201_n1000_first8" if shape == "nb201" else "pc_guided_ofa_n1000_first6")
+    run = (lambda: run_sampler(g, True)) if shape == "nb201" else (lambda: run_sampler_ofa(g))
+    f1, r1 = run()
+    monkeypatch.setenv("DNAG_OVERLAP", "0")
+    f0, r0 = run()
+    host = lambda v: v.detach().cpu() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+    assert torch.equal(host(f0), host(f1))
+    compared = 0
+    for k in ("rec_score_c", "rec_score_p", "rec_cgrad_c", "rec_cgrad_p", "rec_x_corr", "rec_x_pred"):
+        if r0.get(k) is not None:
+            assert torch.equal(host(r0[k]), host(r1[k])), k
+            compared += 1
+    assert compared >= 4
+
+
 def test_full_batch_guided_ofa_step_matches_oracle():
     """BASELINE config 4 shape: B=4096 OFA guided, 1 PC step; every graph of the corrector evaluation and of the
     predictor evaluation against the oracle (teacher-forced on the recorded corrected state)."""
