@@ -1380,9 +1380,34 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     LAUNCH_CHECK();
     hipLaunchKernelGGL(train_pack_layers_kernel, dim3(32, L), dim3(256), 0, st, S, sl, P, tl);
     LAUNCH_CHECK();
+    // The device's second stream (SideStream, above; sw = st when DNAG_OVERLAP=0) takes what hangs off the step's main
+    // chain without feeding its next kernel: here the head weights' scales and backward transposes, which the chain needs
+    // only after the encoder forward (128 workgroups at B = 1024: half the chip is free meanwhile).
+    SideStream *side = nullptr;
+    if (overlap_enabled()) if (int rc = side_for_current_device(&side)) return rc;
+    std::unique_lock<std::mutex> side_lock;
+    if (side) side_lock = std::unique_lock<std::mutex>(side->use);
+    hipStream_t sw = side ? side->st : st;
+    auto fork = [&]() -> int {
+        if (side) { HIP_TRY(hipEventRecord(side->fork, st)); HIP_TRY(hipStreamWaitEvent(side->st, side->fork, 0)); }
+        return 0;
+    };
+    auto join = [&]() -> int {
+        if (side) { HIP_TRY(hipEventRecord(side->join, side->st)); HIP_TRY(hipStreamWaitEvent(st, side->join, 0)); }
+        return 0;
+    };
+    // every operand's power-of-two scale comes from its largest magnitude, measured on the device (no range to respect)
+    HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 8 * sizeof(float), st));
+    float *amax_dh2 = ws + w.amax, *amax_dh1 = ws + w.amax + 1, *amax_w0 = ws + w.amax + 2, *amax_w1 = ws + w.amax + 3;
+    float *amax_cc = ws + w.amax + 4, *amax_h1 = ws + w.amax + 5;
+    if (int rc = fork()) return rc;            // the packed head weights and the cleared scales are in place
+    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, sw, P + e.f0_w, (size_t)Hd * F, amax_w0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, sw, P + e.f1_w, (size_t)Hd * Hd, amax_w1);
+    LAUNCH_CHECK();
     if (p->grads) {
-        if (int rc = launch_transpose(S + sl.f0_w, Hd, F, F, P + tl.f0T, Hd, Hd, st)) return rc;      // [Hd][F] -> [F][Hd]
-        if (int rc = launch_transpose(S + sl.f1_w, Hd, Hd, Hd, P + tl.f1T, Hd, Hd, st)) return rc;
+        if (int rc = launch_transpose(S + sl.f0_w, Hd, F, F, P + tl.f0T, Hd, Hd, sw)) return rc;      // [Hd][F] -> [F][Hd]
+        if (int rc = launch_transpose(S + sl.f1_w, Hd, Hd, Hd, P + tl.f1T, Hd, Hd, sw)) return rc;
     }
     // ---- 1. time embedding per graph, perturbation -----------------------------------------------------------
     hipLaunchKernelGGL(time_embed_train_kernel, dim3(B), dim3(256), (size_t)5 * d * sizeof(float), st, p->labels, d, P + e.freq, P + e.t1_w,
@@ -1402,16 +1427,9 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
         return rc;
     // ---- 3. head MLP and loss ------------------------------------------------------------------------------------
     // all six big GEMMs of the step run on the split-arithmetic fp16 MFMA kernel with fp32 operands split on the fly
-    // every operand's power-of-two scale comes from its largest magnitude, measured on the device (no range to respect)
-    HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 8 * sizeof(float), st));
-    float *amax_dh2 = ws + w.amax, *amax_dh1 = ws + w.amax + 1, *amax_w0 = ws + w.amax + 2, *amax_w1 = ws + w.amax + 3;
-    float *amax_cc = ws + w.amax + 4, *amax_h1 = ws + w.amax + 5;
-    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, st, P + e.f0_w, (size_t)Hd * F, amax_w0);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, st, P + e.f1_w, (size_t)Hd * Hd, amax_w1);
-    LAUNCH_CHECK();
     hipLaunchKernelGGL(amax_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, rows * (size_t)F, amax_cc);
     LAUNCH_CHECK();
+    if (int rc = join()) return rc;            // the weights' scales (and transposes)
     if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.concat, F, amax_cc, P + e.f0_w, F, amax_w0, P + e.f0_b, ws + w.h1, Hd, nullptr, rows_pad, Hd, F, 1, st, amax_h1)) return rc;
     if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.h1, Hd, amax_h1, P + e.f1_w, Hd, amax_w1, P + e.f1_b, ws + w.h2, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
     if (V == 7 && Hd % 4 == 0) {       // out = H2 W3^T + b3, one wave per row
@@ -1434,25 +1452,29 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (!p->grads) return 0;
     float *G = p->grads;
     float *scr = ws + w.scratch;
+    // The head's weight and bias gradients hang off the chain dout -> dH2 -> dH1 -> dconcat -> encoder backward without
+    // feeding it: they run on the second stream, forked where their operands are complete and joined before the
+    // time-embedding gradients, which share their scratch.
     // ---- 4. head backward ------------------------------------------------------------------------------------------
-    if (int rc = launch_tn_small<0>(ws + w.dout, V, ws + w.h2, Hd, rows, w.nz_rows, V, Hd, scr, G + sl.f2_w, st)) return rc;     // dW3 = dout^T H2
-    if (int rc = launch_colsum(ws + w.dout, V, rows, w.nz_rows, V, scr, G + sl.f2_b, st)) return rc;
     hipLaunchKernelGGL((head_out_bwd_kernel<7>), dim3((unsigned)(rows_pad < 2048 ? rows_pad : 2048)), dim3(256), 0, st, ws + w.h2, ws + w.dout,
                        P + e.f2_w, Hd, rows, rows_pad, ws + w.dh2, amax_dh2);
     LAUNCH_CHECK();
-    if (int rc = launch_colsum(ws + w.dh2, Hd, rows, w.nz_rows, Hd, scr, G + sl.f1_b, st)) return rc;
-    if (int rc = launch_transpose(ws + w.dh2, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
-    if (int rc = launch_transpose(ws + w.h1, rows_pad, Hd, Hd, ws + w.T2, rows_pad, rows_pad, st)) return rc;
+    if (int rc = fork()) return rc;            // dout, dH2 and its scale are complete
+    if (int rc = launch_tn_small<0>(ws + w.dout, V, ws + w.h2, Hd, rows, w.nz_rows, V, Hd, scr, G + sl.f2_w, sw)) return rc;     // dW3 = dout^T H2
+    if (int rc = launch_colsum(ws + w.dout, V, rows, w.nz_rows, V, scr, G + sl.f2_b, sw)) return rc;
+    if (int rc = launch_colsum(ws + w.dh2, Hd, rows, w.nz_rows, Hd, scr, G + sl.f1_b, sw)) return rc;
+    if (int rc = launch_transpose(ws + w.dh2, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, sw)) return rc;
+    if (int rc = launch_transpose(ws + w.h1, rows_pad, Hd, Hd, ws + w.T2, rows_pad, rows_pad, sw)) return rc;
     // weight gradients reduce over the rows: few output tiles, long K -> split K so that the grid fills the chip
     auto wgrad_gemm = [&](const float *At, const float *amax_at, const float *Bt, const float *amax_bt, int Mo, int No, float *dst) -> int {
         const int tiles = (Mo / SplitGeom::BM) * (No / SplitGeom::BN);
         int split = 1;
         while (split < 16 && tiles * split < 256 && (rows_pad / GEMM_BK) % (2 * split) == 0) split *= 2;
         if (int rc = launch_gemm32<ACT_NONE, 4>(At, (int)rows_pad, amax_at, Bt, (int)rows_pad, amax_bt, nullptr, ws + w.splitk, No, nullptr, Mo, No,
-                                                (int)rows_pad, split, st))
+                                                (int)rows_pad, split, sw))
             return rc;
         const size_t n = (size_t)Mo * No;
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, st, ws + w.splitk, split, n, n, dst, 1.0f);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, sw, ws + w.splitk, split, n, n, dst, 1.0f);
         return hipGetLastError() == hipSuccess ? 0 : fail(DNAG_E_HIP, "reduce_parts_kernel launch failed");
     };
     if (int rc = wgrad_gemm(ws + w.T1, amax_dh2, ws + w.T2, amax_h1, Hd, Hd, G + sl.f1_w)) return rc;   // dW2 = dH2^T H1
@@ -1460,10 +1482,12 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = launch_gemm32<ACT_NONE, 3>(ws + w.dh2, Hd, amax_dh2, P + tl.f1T, Hd, amax_w1, nullptr, ws + w.dh1, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
     hipLaunchKernelGGL(mul_elugrad_kernel, dim3(2048), dim3(256), 0, st, ws + w.dh1, ws + w.h1, rows_pad * (size_t)Hd / 4, amax_dh1);
     LAUNCH_CHECK();
-    if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, st)) return rc;
-    if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, st)) return rc;
-    if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, st)) return rc;
+    if (int rc = fork()) return rc;            // dH1 and its scale are complete
+    if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, sw)) return rc;
+    if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, sw)) return rc;
+    if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, sw)) return rc;
     if (int rc = wgrad_gemm(ws + w.T1, amax_dh1, ws + w.T2, amax_cc, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
+    if (side) HIP_TRY(hipEventRecord(side->join, side->st));      // awaited before section 6
     if (int rc = launch_gemm32<ACT_NONE, 3>(ws + w.dh1, Hd, amax_dh1, P + tl.f0T, Hd, amax_w0, nullptr, ws + w.dconcat, F, nullptr, rows_pad, F, Hd, 1, st)) return rc;
     // ---- 5. encoder backward -----------------------------------------------------------------------------------------
     if (int rc = train_g(B) == 8 ? launch_train_enc_bwd<8>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st)
@@ -1482,6 +1506,7 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
         hipLaunchKernelGGL(copy_segs_kernel, dim3(2), dim3(256), 0, st, gs);
         LAUNCH_CHECK();
     }
+    if (side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
     // ---- 6. time-embedding MLP backward --------------------------------------------------------------------------------
     hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(B), dim3(256), (size_t)d * sizeof(float), st, ws + w.dtau, ws + w.save_pre, d, P + e.t2_w, ws + w.dpre);
     LAUNCH_CHECK();

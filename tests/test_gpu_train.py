@@ -249,3 +249,32 @@ def test_full_size_batch_properties():
     loss.backward()
     assert np.isfinite(float(loss.detach()))
     assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_second_stream_changes_no_gradient_bit(monkeypatch):
+    """The head's weight gradients run on the library's second stream (dnag_lib.hip SideStream) beside the chain that
+    leads to the encoder backward; DNAG_OVERLAP=0 keeps the step on one stream.  Same kernels, same operands: every
+    gradient and the loss equal, over three steps in a row on the same buffers (an ordering slip would show as a race)."""
+    g = golden("train_nb201_vp_drop")
+    x, t, z, dropout = train_case(g)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    maskB = torch.from_numpy(g["mask"]).unsqueeze(0).repeat(x.shape[0], 1, 1)
+
+    def grads():
+        model = make_model(0)
+        out = []
+        for _ in range(3):
+            loss = run_step(model, sde, x, t, z, maskB, dropout)
+            out.append([float(loss.detach())] + [p.grad.detach().clone() for _, p in model.named_parameters()])
+        return out
+
+    two = grads()
+    monkeypatch.setenv("DNAG_OVERLAP", "0")
+    one = grads()
+    for a, b in zip(one, two):
+        assert a[0] == b[0]
+        for ga, gb in zip(a[1:], b[1:]):
+            assert torch.equal(ga, gb)
+    for a in two[1:]:
+        for ga, gb in zip(a[1:], two[0][1:]):
+            assert torch.equal(ga, gb)
