@@ -1453,8 +1453,8 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     float *G = p->grads;
     float *scr = ws + w.scratch;
     // The head's weight and bias gradients hang off the chain dout -> dH2 -> dH1 -> dconcat -> encoder backward without
-    // feeding it: they run on the second stream, forked where their operands are complete and joined before the
-    // time-embedding gradients, which share their scratch.
+    // feeding it: they run on the second stream, forked where their operands are complete; the time-embedding gradients,
+    // which share their scratch, follow them on that stream (section 6) and the step ends with the join.
     // ---- 4. head backward ------------------------------------------------------------------------------------------
     hipLaunchKernelGGL((head_out_bwd_kernel<7>), dim3((unsigned)(rows_pad < 2048 ? rows_pad : 2048)), dim3(256), 0, st, ws + w.h2, ws + w.dout,
                        P + e.f2_w, Hd, rows, rows_pad, ws + w.dh2, amax_dh2);
@@ -1487,12 +1487,12 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, sw)) return rc;
     if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, sw)) return rc;
     if (int rc = wgrad_gemm(ws + w.T1, amax_dh1, ws + w.T2, amax_cc, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
-    if (side) HIP_TRY(hipEventRecord(side->join, side->st));      // awaited before section 6
     if (int rc = launch_gemm32<ACT_NONE, 3>(ws + w.dh1, Hd, amax_dh1, P + tl.f0T, Hd, amax_w0, nullptr, ws + w.dconcat, F, nullptr, rows_pad, F, Hd, 1, st)) return rc;
     // ---- 5. encoder backward -----------------------------------------------------------------------------------------
     if (int rc = train_g(B) == 8 ? launch_train_enc_bwd<8>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st)
                                  : launch_train_enc_bwd<4>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st))
         return rc;
+    if (int rc = fork()) return rc;            // dtau is complete: section 6 goes to the second stream, behind the head's gradients
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((gl.total + 255) / 256)), dim3(256), 0, st, ws + w.part, w.nblk_enc, gl.total, gl.total,
                        ws + w.gsum, 1.0f);
     LAUNCH_CHECK();
@@ -1506,15 +1506,14 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
         hipLaunchKernelGGL(copy_segs_kernel, dim3(2), dim3(256), 0, st, gs);
         LAUNCH_CHECK();
     }
-    if (side) HIP_TRY(hipStreamWaitEvent(st, side->join, 0));
-    // ---- 6. time-embedding MLP backward --------------------------------------------------------------------------------
-    hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(B), dim3(256), (size_t)d * sizeof(float), st, ws + w.dtau, ws + w.save_pre, d, P + e.t2_w, ws + w.dpre);
+    // ---- 6. time-embedding MLP backward (second stream: beside the reduction of the encoder's partial gradients) --------
+    hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(B), dim3(256), (size_t)d * sizeof(float), sw, ws + w.dtau, ws + w.save_pre, d, P + e.t2_w, ws + w.dpre);
     LAUNCH_CHECK();
-    if (int rc = launch_tn_small<1>(ws + w.dtau, d, ws + w.save_pre, 4 * d, B, w.nz_b, d, 4 * d, scr, G + sl.t2_w, st)) return rc;   // dW2 = dtau^T silu(pre)
-    if (int rc = launch_colsum(ws + w.dtau, d, B, w.nz_b, d, scr, G + sl.t2_b, st)) return rc;
-    if (int rc = launch_tn_small<0>(ws + w.dpre, 4 * d, ws + w.save_e, d, B, w.nz_b, 4 * d, d, scr, G + sl.t1_w, st)) return rc;    // dW1 = dpre^T e
-    if (int rc = launch_colsum(ws + w.dpre, 4 * d, B, w.nz_b, 4 * d, scr, G + sl.t1_b, st)) return rc;
-    return 0;
+    if (int rc = launch_tn_small<1>(ws + w.dtau, d, ws + w.save_pre, 4 * d, B, w.nz_b, d, 4 * d, scr, G + sl.t2_w, sw)) return rc;   // dW2 = dtau^T silu(pre)
+    if (int rc = launch_colsum(ws + w.dtau, d, B, w.nz_b, d, scr, G + sl.t2_b, sw)) return rc;
+    if (int rc = launch_tn_small<0>(ws + w.dpre, 4 * d, ws + w.save_e, d, B, w.nz_b, 4 * d, d, scr, G + sl.t1_w, sw)) return rc;    // dW1 = dpre^T e
+    if (int rc = launch_colsum(ws + w.dpre, 4 * d, B, w.nz_b, 4 * d, scr, G + sl.t1_b, sw)) return rc;
+    return join();
 }
 
 extern "C" size_t dnag_optim_workspace_bytes(void) { return OPTIM_BLOCKS * sizeof(double); }
