@@ -40,7 +40,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0     # same guide: BF16/F16 ~2.5 PF dense (a bare v
 SPLIT_MFMA_PER_PRODUCT = 3
 # Fabric-side bytes of ONE launch of the dominant kernel (final.linears.1 at B=4096, NB201) from PMC counters:
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as the guide's HBM
-# section prescribes for gfx950 (profiles/r03d_pmc_traffic.json: 0.454 GB read + 0.006 GB written; algorithmic
+# section prescribes for gfx950 (profiles/r03f_pmc_traffic.json: 0.454 GB read + 0.006 GB written; algorithmic
 # bytes 0.218 GB = A 201 MB + W 9.4 MB + the fused final.linears.2 partial sums 7.3 MB; the excess is the weight
 # matrix fetched once per XCD and round of tiles, 8 x 3 x 9.4 MB, out of the Infinity Cache).  Counters cannot be collected inside this process, so the figure is quoted only for the shape it
 # was measured on.
@@ -323,8 +323,12 @@ def bench_sampling(a, workload, steps, warmup):
                          "mfma_issued_frac": achieved * SPLIT_MFMA_PER_PRODUCT / PEAK_F16_MFMA_TFLOPS,
                          "achieved_over_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES.get((workload, B)),
-                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03d_pmc_traffic.json)",
-                         "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value},
+                         "traffic_unit": "bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r03f_pmc_traffic.json)",
+                         "launch_ms": mean_ms.value, "launches_timed": n_s.value, "flops_per_launch": flops.value,
+                         "streams": ("the surrogate's gradient runs on the library's second stream beside the score network "
+                                     "(dnag_lib.hip SideStream; DNAG_OVERLAP=0 disables): launch_ms is this kernel's time in "
+                                     "that mix -- alone on the chip for NB201 (0.31 ms on one stream too), shared with the "
+                                     "surrogate's kernels for OFA (0.80 ms on one stream)")},
             "whole_path_tflops": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world,
             "whole_path_frac_of_f32_mfma_peak": value * flop_per_sample * (a.sde_steps / 1000.0) / 1e12 / world / PEAK_F32_MFMA_TFLOPS,
             "outputs_finite": finite,
