@@ -8,6 +8,12 @@
  * the calling thread's last failure.  Nothing here synchronises the host with the device
  * unless the comment says so.
  *
+ * Streams: work is ordered on the `stream` passed in.  dnag_pc_sample (guided) and
+ * dnag_cate_dsm_step also use one stream of the library's own per device (created, with two
+ * events, by the first such call on the device: make it outside a stream capture), forked
+ * from and joined to `stream` by events inside the call; results do not depend on it.
+ * DNAG_OVERLAP=0 in the environment (read at every call) keeps everything on `stream`.
+ *
  * Reference citations are relative to /root/reference/NAS-Bench-201/.
  */
 #ifndef DNAG_H
