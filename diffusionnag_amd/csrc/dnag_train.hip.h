@@ -1062,6 +1062,11 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
     colsum(tmp, HS, D, mypart + gl.emb_b);
 }
 
+__device__ __forceinline__ float tree16(const float (&a)[16]) {
+    return (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+           (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Folded-space gradients (summed over workgroups) -> state_dict order.
 //   W' = W diag(gamma), b' = b + W beta   =>   dW = dW' diag(gamma) + db' beta^T,  d gamma = sum_r dW'[r] . W[r],
@@ -1112,30 +1117,34 @@ __global__ __launch_bounds__(256) void train_unfold_layers_kernel(const float *_
         j -= D;
         if (j < 2 * D) {            // self_attn.norm: gamma (j < D), beta
             const size_t k = j < D ? j : j - D;
-            float acc4[4] = {0.f, 0.f, 0.f, 0.f};     // four independent chains: the loads of a chain overlap
-            for (size_t r0 = 0; r0 < 3 * D; r0 += 4) {
+            // sixteen independent chains, 32 loads in flight: the loop is a string of L2 round trips (57 us with four)
+            float acc[16];
 #pragma unroll
-                for (size_t u = 0; u < 4; ++u) {
-                    const size_t r = r0 + u, which = r / D, rr = r - which * D;
-                    const float w = SL[(which == 0 ? sl.s_wq : which == 1 ? sl.s_wk : sl.s_wv) + rr * D + k];
-                    acc4[u] = fmaf(j < D ? GL[gl.l_wqkv + r * D + k] : GL[gl.l_bqkv + r], w, acc4[u]);
-                }
+            for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+            for (size_t r0 = 0; r0 < 3 * D; r0 += 16) {
+                const size_t which = r0 / D;             // D is a multiple of 16: one of q, k, v per group
+                const float *wsrc = SL + (which == 0 ? sl.s_wq : which == 1 ? sl.s_wk : sl.s_wv) + (r0 - which * D) * D + k;
+#pragma unroll
+                for (size_t u = 0; u < 16; ++u)
+                    acc[u] = fmaf(j < D ? GL[gl.l_wqkv + (r0 + u) * D + k] : GL[gl.l_bqkv + r0 + u], wsrc[u * D], acc[u]);
             }
-            OL[(j < D ? sl.s_ln1g : sl.s_ln1b) + k] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+            OL[(j < D ? sl.s_ln1g : sl.s_ln1b) + k] = tree16(acc);
             continue;
         }
         j -= 2 * D;
         if (j < 2 * D) {            // feed_forward.norm
             const size_t k = j < D ? j : j - D;
-            float acc4[4] = {0.f, 0.f, 0.f, 0.f};
-            for (size_t r0 = 0; r0 < DFF; r0 += 4) {
+            float acc[16];
 #pragma unroll
-                for (size_t u = 0; u < 4; ++u) {
+            for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+            for (size_t r0 = 0; r0 < DFF; r0 += 16) {
+#pragma unroll
+                for (size_t u = 0; u < 16; ++u) {
                     const size_t r = r0 + u;
-                    acc4[u] = fmaf(j < D ? GL[gl.l_w1 + r * D + k] : GL[gl.l_b1 + r], SL[sl.s_w1 + r * D + k], acc4[u]);
+                    acc[u] = fmaf(j < D ? GL[gl.l_w1 + r * D + k] : GL[gl.l_b1 + r], SL[sl.s_w1 + r * D + k], acc[u]);
                 }
             }
-            OL[(j < D ? sl.s_ln2g : sl.s_ln2b) + k] = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+            OL[(j < D ? sl.s_ln2g : sl.s_ln2b) + k] = tree16(acc);
             continue;
         }
         j -= 2 * D;
