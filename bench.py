@@ -136,7 +136,7 @@ def bench_train(a, emit=True):
     dims = CateDims()
     model = mutils.create_model(score_config(dev, dims))
     model.load_state_dict(synthetic.cate_state_dict(dims, seed=0))
-    model.dropout_p = 0.1
+    model.dropout_p = float(os.environ.get("DNAG_BENCH_DROPOUT", "0.1"))   # 0.1 is the workload; 0 times the no-dropout kernels (profiling only)
     sde = sde_lib.VPSDE(0.1, 20.0, 1000)
     g = torch.Generator().manual_seed(0)
     ops = torch.randint(0, 7, (B, 8), generator=g)

@@ -78,8 +78,11 @@ __device__ __forceinline__ void split4(const v4f v, h4 &hi, h4 &lo) {
 // (dnag_cate_dsm_step): the activations the backward pass needs are written to `sv` (EncSave, dnag_encoder.hip.h), the
 // concat is plain fp32 rows [row][F] WITH the output norm's affine (the training head keeps the unfolded weights), and
 // MODE 2 applies the dropout keep masks `dm` at the reference's five sites (cate.py:147, transformer.py:19, :54, :80, :108).
+// The training modes are bounded at one workgroup per CU: the keep words read ahead of each phase's MFMA chain and the
+// save addresses take 268-272 VGPRs (24 spilled registers at the 256 of two workgroups; 173 -> 152 us at B = 1024, and no
+// difference at B = 8192, where the saves' HBM traffic sets the pace).
 template <int N_, int V, int MODE = 0>
-__global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restrict__ P, const CateLayout lay,
+__global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void encoder8_kernel(const float *__restrict__ P, const CateLayout lay,
                                                           const float *__restrict__ x, const float *__restrict__ temb,
                                                           int tstride, const float *__restrict__ mask, int mstride,
                                                           float *__restrict__ concat, int batch, const EncSave sv,
@@ -106,6 +109,17 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
     auto live = [&](int row) { return row < RV && g0 + row / N < batch; };     // a real graph row of this workgroup
+    // saved activations have rows_pad rows (a multiple of 256): with no spare rows in the tile (RV == R) the rows of the
+    // graphs past the batch fall into that padding, and the stores need no condition (conditional stores make every later
+    // s_waitcnt conservative)
+    auto sv_live = [&](int row) { if constexpr (RV == R) return true; else return live(row); };
+    // four keep words (16 keep bytes: columns c .. c + 3 of column groups 0 .. 3, 8 apart) of tile row `row` at one dropout
+    // site, read ahead of the phase's MFMA chain; a row past the batch reads row 0's (its values go nowhere)
+    auto keep4 = [&](const uint8_t *KLp, int row, int c, uint32_t (&kb)[4]) {
+        const uint8_t *src = KLp + (size_t)(live(row) ? row : 0) * dm.per_layer + c;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) kb[gq] = *reinterpret_cast<const uint32_t *>(src + 8 * gq);
+    };
     const size_t rows_pad = ((size_t)batch * N + 255) / 256 * 256;      // the concat is k-tile blocked (dnag_gemm16.hip.h kblock_at)
     const float *P16 = P + lay.delta16;      // fp16 hi/lo fragment copy of the layer matrices
 
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 val = val + temb[(size_t)(tstride ? g0 + g : 0) * D + c];
             }
             emb[rr * AS + c] = val;
-            if constexpr (SAVE) if (live(rr)) sv.h[((size_t)g0 * N + rr) * D + c] = val;
+            if constexpr (SAVE) if (sv_live(rr)) sv.h[((size_t)g0 * N + rr) * D + c] = val;
         }
     }
     __syncthreads();
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                     const int lr = mt * 32 + acc_row(i, h);
                     const float v = acc[i] * inv + bv;
                     qkv[lr * QS + col] = v;
-                    if constexpr (SAVE) if (live(lr)) sv.qkv[((size_t)l * sv.rows + (size_t)g0 * N + lr) * (3 * D) + col] = v;
+                    if constexpr (SAVE) if (sv_live(lr)) sv.qkv[((size_t)l * sv.rows + (size_t)g0 * N + lr) * (3 * D) + col] = v;
                 }
             };
             f32x16 c1 = zero16, c2 = zero16, c3 = zero16;
@@ -446,6 +460,16 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 const int row0 = g * N + 2 * qp;
                 const float sa_o = SC[ENC_SC_SA_O];
                 v2f q[DK];
+                // keep bytes of the two queries' N probabilities of this head, read before anything else of the phase
+                uint32_t kp[2][N / 4];
+                if constexpr (DROP) {                 // transformer.py:19
+                    const uint8_t *src = KL + (size_t)(g0 + g < batch ? row0 : 0) * dm.per_layer + hd * N;
+#pragma unroll
+                    for (int e = 0; e < N / 4; ++e) {
+                        kp[0][e] = *reinterpret_cast<const uint32_t *>(src + 4 * e);
+                        kp[1][e] = *reinterpret_cast<const uint32_t *>(src + dm.per_layer + 4 * e);
+                    }
+                }
                 {
                     const float *qa = qkv + row0 * QS + hd * DK, *qb = qa + QS;
 #pragma unroll
@@ -497,11 +521,9 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     v2f p = s[j] * rden;
-                    if constexpr (DROP) {            // transformer.py:19
-                        if (g0 + g < batch) {
-                            p.x = drop_apply(p.x, KL[(size_t)row0 * dm.per_layer + hd * N + j], dm.keep_prob);
-                            p.y = drop_apply(p.y, KL[(size_t)(row0 + 1) * dm.per_layer + hd * N + j], dm.keep_prob);
-                        }
+                    if constexpr (DROP) {
+                        p.x = drop_apply(p.x, (uint8_t)(kp[0][j >> 2] >> (8 * (j & 3))), dm.keep_prob);
+                        p.y = drop_apply(p.y, (uint8_t)(kp[1][j >> 2] >> (8 * (j & 3))), dm.keep_prob);
                     }
                     const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK;
 #pragma unroll
@@ -640,6 +662,8 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             const float inv = SC[ENC_SC_INV_O];
             afrag_t xa;
             load_a64(a16 + (tmt * 32 + r) * AS + h * (D / 2), xa);
+            uint32_t kb3[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+            if constexpr (DROP) keep4(KL, tmt * 32 + r, H * N + tnt * 32 + 4 * h, kb3);      // transformer.py:80
             E8_PIN();
             f32x16 acc = zero16;
             E8_SUB();
@@ -652,15 +676,14 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 const int c0 = tnt * 32 + 8 * gq + 4 * h;
                 const v4f b4 = *reinterpret_cast<const v4f *>(bst + 3 * D + c0);
                 const int lr = tmt * 32 + r;
-                uint32_t kb = 0x01010101u;
-                if constexpr (DROP) if (live(lr)) kb = *reinterpret_cast<const uint32_t *>(KL + (size_t)lr * dm.per_layer + H * N + c0);   // transformer.py:80
+                const uint32_t kb = kb3[gq];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float yv = acc[4 * gq + e] * inv + b4[e];
                     if constexpr (DROP) yv = drop_apply(yv, (uint8_t)(kb >> (8 * e)), dm.keep_prob);
                     hacc[4 * gq + e] = yv + hacc[4 * gq + e];
                 }
-                if constexpr (SAVE) if (live(lr))
+                if constexpr (SAVE) if (sv_live(lr))
                     *reinterpret_cast<v4f *>(sv.h1 + ((size_t)l * sv.rows + (size_t)g0 * N + lr) * D + c0) =
                         v4f{hacc[4 * gq], hacc[4 * gq + 1], hacc[4 * gq + 2], hacc[4 * gq + 3]};
             }
@@ -689,6 +712,11 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
             v4f bias4[4];
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) bias4[gq] = *reinterpret_cast<const v4f *>(b1p + 8 * gq);
+            uint32_t kb5[2][4] = {{0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u}, {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u}};
+            if constexpr (DROP) {                                                               // transformer.py:54
+                keep4(KL, r, H * N + D + nt * 32 + 4 * h, kb5[0]);
+                keep4(KL, 32 + r, H * N + D + nt * 32 + 4 * h, kb5[1]);
+            }
             E8_PIN();
             auto put = [&](const f32x16 &acc, int mt) {
                 _Float16 *hrow = reinterpret_cast<_Float16 *>(hid + (mt * 32 + r) * FS);
@@ -696,15 +724,14 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 for (int gq = 0; gq < 4; ++gq) {
                     v4f f;
                     const int lr = mt * 32 + r, c0 = nt * 32 + 8 * gq + 4 * h;
-                    uint32_t kb = 0x01010101u;
-                    if constexpr (DROP) if (live(lr)) kb = *reinterpret_cast<const uint32_t *>(KL + (size_t)lr * dm.per_layer + H * N + D + c0);   // transformer.py:54
+                    const uint32_t kb = kb5[mt][gq];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float fv = fmaxf(acc[4 * gq + e] * inv + bias4[gq][e], 0.f);
                         if constexpr (DROP) fv = drop_apply(fv, (uint8_t)(kb >> (8 * e)), dm.keep_prob);
                         f[e] = fv;
                     }
-                    if constexpr (SAVE) if (live(lr)) *reinterpret_cast<v4f *>(sv.f + ((size_t)l * sv.rows + (size_t)g0 * N + lr) * DFF + c0) = f;
+                    if constexpr (SAVE) if (sv_live(lr)) *reinterpret_cast<v4f *>(sv.f + ((size_t)l * sv.rows + (size_t)g0 * N + lr) * DFF + c0) = f;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) f[e] *= sa_f2;
                     h4 hi, lo;
@@ -757,6 +784,8 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 acc = mfma16(bhi, a[s][1], acc); hook(3 * s + 2); E8_HOLD();
             };
             ld(0); ld(1); ld(2); ld(3);
+            uint32_t kb6[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+            if constexpr (DROP) keep4(KL, tmt * 32 + r, H * N + D + DFF + tnt * 32 + 4 * h, kb6);      // transformer.py:108
             E8_PIN();
             f32x16 acc = zero16;
             E8_SUB();
@@ -774,15 +803,14 @@ __global__ __launch_bounds__(256, 2) void encoder8_kernel(const float *__restric
                 const int c0 = tnt * 32 + 8 * gq + 4 * h;
                 const v4f b4 = *reinterpret_cast<const v4f *>(bst + 4 * D + DFF + c0);
                 const int lr = tmt * 32 + r;
-                uint32_t kb = 0x01010101u;
-                if constexpr (DROP) if (live(lr)) kb = *reinterpret_cast<const uint32_t *>(KL + (size_t)lr * dm.per_layer + H * N + D + DFF + c0);   // transformer.py:108
+                const uint32_t kb = kb6[gq];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float yv = acc[4 * gq + e] * inv + b4[e];
                     if constexpr (DROP) yv = drop_apply(yv, (uint8_t)(kb >> (8 * e)), dm.keep_prob);
                     hacc[4 * gq + e] = yv + hacc[4 * gq + e];
                 }
-                if constexpr (SAVE) if (live(lr))
+                if constexpr (SAVE) if (sv_live(lr))
                     *reinterpret_cast<v4f *>(sv.h + ((size_t)(l + 1) * sv.rows + (size_t)g0 * N + lr) * D + c0) =
                         v4f{hacc[4 * gq], hacc[4 * gq + 1], hacc[4 * gq + 2], hacc[4 * gq + 3]};
             }
