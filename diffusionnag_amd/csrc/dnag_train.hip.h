@@ -751,16 +751,31 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
         }
     };
     // dst[r][c] = Dk(src[r][c]) for a 64-wide site at byte offset `off` of the layer slab (0 for dead rows)
+    // (four columns per thread: the keep bytes of every quad the thread handles are read first, as words, without a
+    // condition -- a dead row reads the workgroup's row 0 -- so that their round trips overlap)
     auto drop_rows = [&](const float *src, float *dst, const uint8_t *KL, int kstride, int off, float scale) {
-        for (int i = tid; i < RP * D; i += 256) {
-            const int r = i >> 6, c = i & 63;
-            float v = 0.f;
+        constexpr int NQ = RP * (D / 4) / 256;
+        static_assert(RP * (D / 4) % 256 == 0 && D == 64, "whole passes of 256 quads");
+        uint32_t kb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = tid + 256 * q, r = i >> 4, c = (i & 15) * 4;
+            kb[q] = 0x01010101u;
+            if (drop) kb[q] = *reinterpret_cast<const uint32_t *>(KL + (size_t)(row0 + (live(r) ? r : 0)) * kstride + off + c);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int i = tid + 256 * q, r = i >> 4, c = (i & 15) * 4;
+            v4f v = v4f{0.f, 0.f, 0.f, 0.f};
             if (live(r)) {
-                v = src[r * HS + c];
-                if (drop) v = drop_apply(v, KL[(row0 + r) * kstride + off + c], kp);
-                v *= scale;
+                v = *reinterpret_cast<const v4f *>(src + r * HS + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (drop) v[e] = drop_apply(v[e], (uint8_t)(kb[q] >> (8 * e)), kp);
+                    v[e] *= scale;
+                }
             }
-            dst[r * HS + c] = v;
+            *reinterpret_cast<v4f *>(dst + r * HS + c) = v;
         }
     };
 
@@ -841,13 +856,20 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
             run_jobs<D, MT, 4>(DFF / 32, tmp, HS, [&](int nt, int, int, float (&b)[D / 2]) { load_frag<D>(W, nt, b); }, ident,
                                [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                                    const int col = nt * 32 + r;
+                                   uint8_t kb[16];              // read first, without a condition (a dead row: row 0's)
+#pragma unroll
+                                   for (int i = 0; i < 16; ++i) {
+                                       const int lr = mt * 32 + acc_row(i, h);
+                                       kb[i] = 1;
+                                       if (drop) kb[i] = KL[(size_t)(row0 + (live(lr) ? lr : 0)) * PL + OFF_FH + col];
+                                   }
 #pragma unroll
                                    for (int i = 0; i < 16; ++i) {
                                        const int lr = mt * 32 + acc_row(i, h);
                                        float g = 0.f;
                                        if (live(lr) && fb[lr * FS + col] > 0.f) {
                                            g = acc[i];
-                                           if (drop) g = drop_apply(g, KL[(row0 + lr) * PL + OFF_FH + col], kp);
+                                           if (drop) g = drop_apply(g, kb[i], kp);
                                        }
                                        fb[lr * FS + col] = g;
                                    }
@@ -906,6 +928,23 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
                 const int row = g * N + n;
                 // as query n: P[n][:] as the forward computes it, a = Dk(P), o_n = a v, dS[n][:], dq_n
                 float q[DK], o[DK], oo[DK];
+                // keep bytes of P[n][:], read before the scores (a graph past the batch: row 0's, unused)
+                const bool lv = g0 + g < batch;
+                const bool ka = drop && lv;
+                uint8_t kbn[N];
+                if (drop) {
+                    const uint8_t *src = KL + (size_t)(row0 + (lv ? row : 0)) * PL + hd * N;
+                    if constexpr (N % 4 == 0) {
+#pragma unroll
+                        for (int j = 0; j < N; j += 4) {
+                            const uint32_t w = *reinterpret_cast<const uint32_t *>(src + j);
+                            kbn[j] = (uint8_t)w; kbn[j + 1] = (uint8_t)(w >> 8); kbn[j + 2] = (uint8_t)(w >> 16); kbn[j + 3] = (uint8_t)(w >> 24);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) kbn[j] = src[j];
+                    }
+                }
                 load_row<DK>(qb + row * QS + hd * DK, q);
                 load_row<DK>(ob + row * HS + hd * DK, o);
                 float s[N], dp[N];
@@ -933,13 +972,11 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
                 float den = 0.f;
 #pragma unroll
                 for (int j = 0; j < N; ++j) { s[j] = __expf(s[j] - mx); den += s[j]; }
-                const bool lv = g0 + g < batch;
-                const uint8_t *ka = (drop && lv) ? KL + (row0 + row) * PL + hd * N : nullptr;
                 float c = 0.f;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     s[j] = s[j] * (1.0f / den);
-                    if (ka) dp[j] = drop_apply(dp[j], ka[j], kp);     // d loss / d P[n][j]
+                    if (ka) dp[j] = drop_apply(dp[j], kbn[j], kp);     // d loss / d P[n][j]
                     c = fmaf(s[j], dp[j], c);
                 }
 #pragma unroll
@@ -950,7 +987,7 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
                 for (int j = 0; j < N; ++j) {
                     // masked_fill (transformer.py:16) passes no gradient to a filled score
                     const float ds = (maskb[(g * N + n) * N + j] == 0.f) ? 0.f : s[j] * (dp[j] - c) * (1.0f / sqrtf((float)DK));
-                    const float a = ka ? drop_apply(s[j], ka[j], kp) : s[j];
+                    const float a = ka ? drop_apply(s[j], kbn[j], kp) : s[j];
                     Pr[j] = a;
                     Sr[j] = ds;
                     const float *kp_ = qb + (g * N + j) * QS + D + hd * DK;
