@@ -256,7 +256,9 @@ typedef struct dnag_pc_args {
      * [langevin_world][that many floats] in rank order (RCCL all_gather; 8 KB per rank at 8192 graphs), and (iii) reduces
      * langevin_global in the fixed order a single batch of langevin_world * batch graphs would use: the step size is then
      * bit-identical to the unsharded run's.  All shards must hold the same number of graphs, a multiple of 8 (NAS-Bench-201)
-     * or 3 (OFA).  NULL: per-shard batch means, no callback. */
+     * or 3 (OFA).  NULL: per-shard batch means, no callback.  The callback runs on the calling thread while
+     * dnag_pc_sample holds the device's second-stream lock (header comment, "Streams"): it must not call
+     * dnag_pc_sample or dnag_cate_dsm_step for the same device. */
     dnag_langevin_exchange_fn langevin_exchange;
     void *langevin_user;
     float *langevin_local;             /* device */
