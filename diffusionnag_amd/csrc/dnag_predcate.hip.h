@@ -160,28 +160,36 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
             }
         }
         __syncthreads();
-        // ---- attention backward, one thread per (graph, head, node) -------------------------------------
+        // ---- attention backward: SP lanes per (graph, head, node), each DK / SP of the head's dimensions --------
+        // (two heads of 32: one lane per item left 120 of the 256 threads with 96 accumulators each; two lanes per item
+        // halve the registers, the LDS reads and the FMAs of a lane, and all four waves work.  The two partial dot
+        // products of a score meet through one DPP exchange.)
         {
-            const bool act = tid < G * H * N;
-            const int it = act ? tid : 0;
+            constexpr int SP = (2 * G * H * N <= 256 && DK % 8 == 0) ? 2 : 1;
+            constexpr int DS = DK / SP;
+            const bool act = tid < G * H * N * SP;
+            const int it = act ? tid / SP : 0;
+            const int eo = (SP == 2 ? (tid & 1) : 0) * DS;          // this lane's first dimension of the head
             const int n = it % N, hd = (it / N) % H, g = it / (N * H);
             const int row = g * N + n;
             const float *Pg = Pm + (g * H + hd) * N * N;
-            float dq[DK], dk[DK], dv[DK];
+            float dq[DS], dk[DS], dv[DS];
+            auto both = [&](float v) { if constexpr (SP == 2) v += dpp_mov<0xB1>(v); return v; };   // quad_perm [1,0,3,2]
             if (act) {
-                // as query n: P[n][:] exactly as the forward computes it, dS[n][:], dq_n
-                float q[DK], o[DK];
-                load_row<DK>(qb + row * QS + hd * DK, q);
-                load_row<DK>(tmp + row * HS + hd * DK, o);
+                // as query n: P[n][:] as the forward computes it (up to the order of the score's sum), dS[n][:], dq_n
+                // (an item's two lanes are both inside or both outside this branch: the DPP exchange has its partner)
+                float q[DS], o[DS];
+                load_row<DS>(qb + row * QS + hd * DK + eo, q);
+                load_row<DS>(tmp + row * HS + hd * DK + eo, o);
                 float s[N], dp[N];
                 float mx = -3.0e38f;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float *kp = qb + (g * N + j) * QS + D + hd * DK;
+                    const float *kp = qb + (g * N + j) * QS + D + hd * DK + eo;
                     const float *vp = kp + D;
                     float acc = 0.f, accv = 0.f;
 #pragma unroll
-                    for (int e = 0; e < DK; e += 4) {
+                    for (int e = 0; e < DS; e += 4) {
                         const v4f k4 = *reinterpret_cast<const v4f *>(kp + e);
                         const v4f v4 = *reinterpret_cast<const v4f *>(vp + e);
                         acc = fmaf(q[e], k4.x, acc); acc = fmaf(q[e + 1], k4.y, acc);
@@ -189,11 +197,14 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
                         accv = fmaf(o[e], v4.x, accv); accv = fmaf(o[e + 1], v4.y, accv);
                         accv = fmaf(o[e + 2], v4.z, accv); accv = fmaf(o[e + 3], v4.w, accv);
                     }
+                    acc = both(acc);
+                    accv = both(accv);
                     acc = acc * (1.0f / sqrtf((float)DK));    // constant-folded reciprocal
                     if (maskb[(g * N + n) * N + j] == 0.f) acc = -1e9f;
                     s[j] = acc;
                     dp[j] = accv;
                     mx = fmaxf(mx, acc);
+                    if ((j & 1) == 1) __builtin_amdgcn_sched_barrier(0);     // two keys' rows in flight, not all twenty
                 }
                 float den = 0.f;
 #pragma unroll
@@ -202,22 +213,22 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
 #pragma unroll
                 for (int j = 0; j < N; ++j) { s[j] = s[j] * (1.0f / den); c = fmaf(s[j], dp[j], c); }
 #pragma unroll
-                for (int e = 0; e < DK; ++e) dq[e] = 0.f;
+                for (int e = 0; e < DS; ++e) dq[e] = 0.f;
                 float *Pr = Pm + ((g * H + hd) * N + n) * N;
                 float *Sr = Sm + ((g * H + hd) * N + n) * N;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     // masked_fill (transformer.py:16) passes no gradient to a filled score
                     const float ds = (maskb[(g * N + n) * N + j] == 0.f) ? 0.f : s[j] * (dp[j] - c) * (1.0f / sqrtf((float)DK));
-                    Pr[j] = s[j];
-                    Sr[j] = ds;
-                    const float *kp = qb + (g * N + j) * QS + D + hd * DK;
+                    if (eo == 0) { Pr[j] = s[j]; Sr[j] = ds; }
+                    const float *kp = qb + (g * N + j) * QS + D + hd * DK + eo;
 #pragma unroll
-                    for (int e = 0; e < DK; e += 4) {
+                    for (int e = 0; e < DS; e += 4) {
                         const v4f k4 = *reinterpret_cast<const v4f *>(kp + e);
                         dq[e] = fmaf(ds, k4.x, dq[e]); dq[e + 1] = fmaf(ds, k4.y, dq[e + 1]);
                         dq[e + 2] = fmaf(ds, k4.z, dq[e + 2]); dq[e + 3] = fmaf(ds, k4.w, dq[e + 3]);
                     }
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
@@ -225,13 +236,13 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
                 // as key/value n: dk_n = sum_i dS[i][n] q_i, dv_n = sum_i P[i][n] dO_i
                 const float *Sg = Sm + (g * H + hd) * N * N;
 #pragma unroll
-                for (int e = 0; e < DK; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
+                for (int e = 0; e < DS; ++e) { dk[e] = 0.f; dv[e] = 0.f; }
                 for (int i = 0; i < N; ++i) {
                     const float ds = Sg[i * N + n], p = Pg[i * N + n];
-                    const float *qp = qb + (g * N + i) * QS + hd * DK;
-                    const float *op = tmp + (g * N + i) * HS + hd * DK;
+                    const float *qp = qb + (g * N + i) * QS + hd * DK + eo;
+                    const float *op = tmp + (g * N + i) * HS + hd * DK + eo;
 #pragma unroll
-                    for (int e = 0; e < DK; e += 4) {
+                    for (int e = 0; e < DS; e += 4) {
                         const v4f q4 = *reinterpret_cast<const v4f *>(qp + e);
                         const v4f o4 = *reinterpret_cast<const v4f *>(op + e);
                         dk[e] = fmaf(ds, q4.x, dk[e]); dk[e + 1] = fmaf(ds, q4.y, dk[e + 1]);
@@ -243,9 +254,9 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
             }
             __syncthreads();
             if (act) {
-                float *qp = qb + row * QS + hd * DK;
+                float *qp = qb + row * QS + hd * DK + eo;
 #pragma unroll
-                for (int e = 0; e < DK; e += 4) {
+                for (int e = 0; e < DS; e += 4) {
                     *reinterpret_cast<v4f *>(qp + e) = v4f{dq[e], dq[e + 1], dq[e + 2], dq[e + 3]};
                     *reinterpret_cast<v4f *>(qp + D + e) = v4f{dk[e], dk[e + 1], dk[e + 2], dk[e + 3]};
                     *reinterpret_cast<v4f *>(qp + 2 * D + e) = v4f{dv[e], dv[e + 1], dv[e + 2], dv[e + 3]};
