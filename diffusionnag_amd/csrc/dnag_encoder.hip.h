@@ -392,25 +392,32 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
         __syncthreads();
         ENC_STAMP();
         // ---- attention per (graph, head, query) ---------------------------------------------------
+        // SP lanes per (graph, head, query) item, DK / SP of the head's dimensions each: with few wide heads (the OFA
+        // surrogate: 2 heads of 32, 120 items) one lane per item leaves half the threads idle with 64 registers of q and o
+        // each; the lanes' partial dot products meet through one DPP exchange (both get the same sum)
+        constexpr int SP = (N > 8 && !DROP && 2 * G * H * N <= 256 && DK % 8 == 0) ? 2 : 1;
+        constexpr int DS = DK / SP;
         if (!(DNAG_ENC_SKIP & 2))
-        for (int it = tid; it < G * H * N; it += 256) {
+        for (int t2 = tid; t2 < G * H * N * SP; t2 += 256) {
+            const int it = t2 / SP, eo = (t2 % SP) * DS;
             const int i = it % N, hd = (it / N) % H, g = it / (N * H);
             const int row = g * N + i;
-            float q[DK];
-            load_row<DK>(qkv + row * QS + hd * DK, q);
+            float q[DS];
+            load_row<DS>(qkv + row * QS + hd * DK + eo, q);
             if constexpr (N > 8 && !DROP) {
                 // Larger graphs: the N scores are not kept (N registers per item, and fully unrolled key loops, pushed the
                 // weight prefetches into scratch); they are computed twice instead, once for the row maximum and once
                 // for exp / sum / P V, with the normalisation applied to the 8 outputs at the end.
                 auto score = [&](int j) {
-                    const float *kp = qkv + (g * N + j) * QS + D + hd * DK;
+                    const float *kp = qkv + (g * N + j) * QS + D + hd * DK + eo;
                     float acc = 0.f;
 #pragma unroll
-                    for (int e = 0; e < DK; e += 4) {
+                    for (int e = 0; e < DS; e += 4) {
                         const v4f v4 = *reinterpret_cast<const v4f *>(kp + e);
                         acc = fmaf(q[e], v4.x, acc); acc = fmaf(q[e + 1], v4.y, acc);
                         acc = fmaf(q[e + 2], v4.z, acc); acc = fmaf(q[e + 3], v4.w, acc);
                     }
+                    if constexpr (SP == 2) acc += dpp_mov<0xB1>(acc);      // quad_perm [1,0,3,2]: the item's other lane
                     acc = acc * (1.0f / sqrtf((float)DK));
                     return maskb[(g * N + i) * N + j] == 0.f ? -1e9f : acc;
                 };
@@ -418,16 +425,16 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
 #pragma unroll 4
                 for (int j = 0; j < N; ++j) mx = fmaxf(mx, score(j));
                 float den = 0.f;
-                float o[DK];
+                float o[DS];
 #pragma unroll
-                for (int e = 0; e < DK; ++e) o[e] = 0.f;
+                for (int e = 0; e < DS; ++e) o[e] = 0.f;
 #pragma unroll 4
                 for (int j = 0; j < N; ++j) {
                     const float p = __expf(score(j) - mx);
                     den += p;
-                    const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK;
+                    const float *vp = qkv + (g * N + j) * QS + 2 * D + hd * DK + eo;
 #pragma unroll
-                    for (int e = 0; e < DK; e += 4) {
+                    for (int e = 0; e < DS; e += 4) {
                         const v4f v4 = *reinterpret_cast<const v4f *>(vp + e);
                         o[e] = fmaf(p, v4.x, o[e]); o[e + 1] = fmaf(p, v4.y, o[e + 1]);
                         o[e + 2] = fmaf(p, v4.z, o[e + 2]); o[e + 3] = fmaf(p, v4.w, o[e + 3]);
@@ -435,11 +442,13 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                 }
                 const float rden = 1.0f / den;
                 if (attn0 != nullptr && l == 0 && g0 + g < batch)
-                    for (int j = 0; j < N; ++j)
-                        attn0[(((size_t)(g0 + g) * H + hd) * N + i) * N + j] = __expf(score(j) - mx) * rden;
-                float *op = qkv + row * QS + hd * DK;   // overwrite this item's own q slot
+                    for (int j = 0; j < N; ++j) {
+                        const float pj = __expf(score(j) - mx) * rden;        // both lanes take part in the exchange
+                        if (eo == 0) attn0[(((size_t)(g0 + g) * H + hd) * N + i) * N + j] = pj;
+                    }
+                float *op = qkv + row * QS + hd * DK + eo;   // overwrite this item's own q slot
 #pragma unroll
-                for (int e = 0; e < DK; e += 4) *reinterpret_cast<v4f *>(op + e) = v4f{o[e] * rden, o[e + 1] * rden, o[e + 2] * rden, o[e + 3] * rden};
+                for (int e = 0; e < DS; e += 4) *reinterpret_cast<v4f *>(op + e) = v4f{o[e] * rden, o[e + 1] * rden, o[e + 2] * rden, o[e + 3] * rden};
                 continue;
             }
             float s[N];
