@@ -71,15 +71,20 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
     //   xh = (x - m) rs;  dx = rs (g - mean(g) - xh mean(g xh))
     auto ln_bwd = [&](const float *xsrc, auto getg) {
         const int sub = tid & 15, slot = tid >> 4;
+        // every pass's row is requested before the first is used (a dead row reads the workgroup's row 0 and is zeroed)
+        v4f xs[RP / 16], gs[RP / 16];
+#pragma unroll
+        for (int p = 0; p < RP / 16; ++p) {
+            const int r = slot + 16 * p, rr = live(r) ? r : 0;
+            xs[p] = *reinterpret_cast<const v4f *>(xsrc + (row0 + rr) * D + 4 * sub);
+            gs[p] = getg(rr, sub);
+        }
 #pragma unroll
         for (int p = 0; p < RP / 16; ++p) {
             const int r = slot + 16 * p;
             const bool lv = live(r);
-            v4f xv = v4f{0.f, 0.f, 0.f, 0.f}, gv = v4f{0.f, 0.f, 0.f, 0.f};
-            if (lv) {
-                xv = *reinterpret_cast<const v4f *>(xsrc + (row0 + r) * D + 4 * sub);
-                gv = getg(r, sub);
-            }
+            v4f xv = xs[p], gv = gs[p];
+            if (!lv) { xv = v4f{0.f, 0.f, 0.f, 0.f}; gv = v4f{0.f, 0.f, 0.f, 0.f}; }
             const float m = row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 64.0f);
             xv.x -= m; xv.y -= m; xv.z -= m; xv.w -= m;
             const float var = row16_sum((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / 64.0f);
@@ -120,11 +125,16 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
             run_jobs<D, MT, 4>(DFF / 32, dH, HS, [&](int nt, int, int, float (&b)[D / 2]) { load_frag<D>(W, nt, b); }, ident,
                                [&](int mt, int nt, int r, int h, const f32x16 &acc) {
                                    const int col = nt * 32 + r;
+                                   float fv[16];                 // all sixteen requested before the first is used
 #pragma unroll
                                    for (int i = 0; i < 16; ++i) {
                                        const int lr = mt * 32 + acc_row(i, h);
-                                       const float fv = live(lr) ? fsv[(size_t)lr * DFF + col] : 0.f;
-                                       fb[lr * FS + col] = fv > 0.f ? acc[i] : 0.f;
+                                       fv[i] = fsv[(size_t)(live(lr) ? lr : 0) * DFF + col];
+                                   }
+#pragma unroll
+                                   for (int i = 0; i < 16; ++i) {
+                                       const int lr = mt * 32 + acc_row(i, h);
+                                       fb[lr * FS + col] = (live(lr) && fv[i] > 0.f) ? acc[i] : 0.f;
                                    }
                                });
         }
@@ -152,11 +162,21 @@ __global__ __launch_bounds__(256, 1) void predcate_enc_bwd_kernel(const float *_
                                    for (int i = 0; i < 16; ++i) tmp[(mt * 32 + acc_row(i, h)) * HS + col] = acc[i];
                                });
             const float *qsv = sv.qkv + ((size_t)l * sv.rows + row0) * (3 * D);
-            for (int i = tid; i < RP * (3 * D / 4); i += 256) {
-                const int r = i / (3 * D / 4), c4 = i - r * (3 * D / 4);
-                v4f v = v4f{0.f, 0.f, 0.f, 0.f};
-                if (live(r)) v = *reinterpret_cast<const v4f *>(qsv + (size_t)r * (3 * D) + 4 * c4);
-                *reinterpret_cast<v4f *>(qb + r * QS + 4 * c4) = v;
+            // four quads per thread requested before the first is stored (a dead row reads row 0 and is zeroed)
+            constexpr int NQ = RP * (3 * D / 4) / 256;
+            static_assert(RP * (3 * D / 4) % 256 == 0 && NQ % 4 == 0, "whole passes of four quads per thread");
+            for (int q0 = 0; q0 < NQ; q0 += 4) {
+                v4f v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid + 256 * (q0 + u), r = i / (3 * D / 4), c4 = i - r * (3 * D / 4);
+                    v[u] = *reinterpret_cast<const v4f *>(qsv + (size_t)(live(r) ? r : 0) * (3 * D) + 4 * c4);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = tid + 256 * (q0 + u), r = i / (3 * D / 4), c4 = i - r * (3 * D / 4);
+                    *reinterpret_cast<v4f *>(qb + r * QS + 4 * c4) = live(r) ? v[u] : v4f{0.f, 0.f, 0.f, 0.f};
+                }
             }
         }
         __syncthreads();
