@@ -698,15 +698,20 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
     // dH[r] += LayerNorm^T(g): xh = (x - m) rs;  dx = rs (g - mean(g) - xh mean(g xh))
     auto ln_bwd = [&](const float *xsrc, auto getg) {
         const int sub = tid & 15, slot = tid >> 4;
+        // every pass's row is requested before the first is used (a dead row reads the workgroup's row 0 and is zeroed)
+        v4f xs[RP / 16], gs[RP / 16];
+#pragma unroll
+        for (int p = 0; p < RP / 16; ++p) {
+            const int r = slot + 16 * p, rr = live(r) ? r : 0;
+            xs[p] = *reinterpret_cast<const v4f *>(xsrc + (row0 + rr) * D + 4 * sub);
+            gs[p] = getg(rr, sub);
+        }
 #pragma unroll
         for (int p = 0; p < RP / 16; ++p) {
             const int r = slot + 16 * p;
             const bool lv = live(r);
-            v4f xv = v4f{0.f, 0.f, 0.f, 0.f}, gv = v4f{0.f, 0.f, 0.f, 0.f};
-            if (lv) {
-                xv = *reinterpret_cast<const v4f *>(xsrc + (row0 + r) * D + 4 * sub);
-                gv = getg(r, sub);
-            }
+            v4f xv = xs[p], gv = gs[p];
+            if (!lv) { xv = v4f{0.f, 0.f, 0.f, 0.f}; gv = v4f{0.f, 0.f, 0.f, 0.f}; }
             const float m = row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 64.0f);
             xv.x -= m; xv.y -= m; xv.z -= m; xv.w -= m;
             const float var = row16_sum((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / 64.0f);
@@ -726,11 +731,16 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
     // dst[r] = LayerNorm without affine of xsrc[row0 + r] (0 for dead rows)
     auto ln_hat = [&](const float *xsrc, float *dst) {
         const int sub = tid & 15, slot = tid >> 4;
+        v4f xs[RP / 16];
 #pragma unroll
         for (int p = 0; p < RP / 16; ++p) {
             const int r = slot + 16 * p;
-            v4f xv = v4f{0.f, 0.f, 0.f, 0.f};
-            if (live(r)) xv = *reinterpret_cast<const v4f *>(xsrc + (row0 + r) * D + 4 * sub);
+            xs[p] = *reinterpret_cast<const v4f *>(xsrc + (row0 + (live(r) ? r : 0)) * D + 4 * sub);
+        }
+#pragma unroll
+        for (int p = 0; p < RP / 16; ++p) {
+            const int r = slot + 16 * p;
+            v4f xv = live(r) ? xs[p] : v4f{0.f, 0.f, 0.f, 0.f};
             const float m = row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 64.0f);
             xv.x -= m; xv.y -= m; xv.z -= m; xv.w -= m;
             const float var = row16_sum((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / 64.0f);
@@ -791,15 +801,19 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
             const int sub = tid & 15, slot = tid >> 4;
             const v4f g4 = *reinterpret_cast<const v4f *>(og + 4 * sub);
             v4f ag = v4f{0.f, 0.f, 0.f, 0.f}, ab = v4f{0.f, 0.f, 0.f, 0.f};
+            v4f xs[RP / 16], ds[RP / 16];
+#pragma unroll
+            for (int p = 0; p < RP / 16; ++p) {
+                const int r = slot + 16 * p, rr = live(r) ? r : 0;
+                xs[p] = *reinterpret_cast<const v4f *>(xsrc + (row0 + rr) * D + 4 * sub);
+                ds[p] = *reinterpret_cast<const v4f *>(dconcat + (row0 + rr) * F + l * D + 4 * sub);
+            }
 #pragma unroll
             for (int p = 0; p < RP / 16; ++p) {
                 const int r = slot + 16 * p;
                 const bool lv = live(r);
-                v4f xv = v4f{0.f, 0.f, 0.f, 0.f}, dc = v4f{0.f, 0.f, 0.f, 0.f};
-                if (lv) {
-                    xv = *reinterpret_cast<const v4f *>(xsrc + (row0 + r) * D + 4 * sub);
-                    dc = *reinterpret_cast<const v4f *>(dconcat + (row0 + r) * F + l * D + 4 * sub);
-                }
+                v4f xv = xs[p], dc = ds[p];
+                if (!lv) { xv = v4f{0.f, 0.f, 0.f, 0.f}; dc = v4f{0.f, 0.f, 0.f, 0.f}; }
                 const float m = row16_sum((xv.x + xv.y) + (xv.z + xv.w)) * (1.0f / 64.0f);
                 xv.x -= m; xv.y -= m; xv.z -= m; xv.w -= m;
                 const float var = row16_sum((xv.x * xv.x + xv.y * xv.y) + (xv.z * xv.z + xv.w * xv.w)) * (1.0f / 64.0f);
@@ -898,6 +912,7 @@ __global__ __launch_bounds__(256, 1) void cate_enc_bwd_kernel(const float *__res
         drop_rows(dH, tmp, KL, PL, OFF_SA, 1.0f);
         {
             const float *qsv = sv.qkv + ((size_t)l * sv.rows + row0) * (3 * D);
+            // (requesting these in batches, as the LayerNorm rows above, was slower here: 608 -> 636 us)
             for (int i = tid; i < RP * (3 * D / 4); i += 256) {
                 const int r = i / (3 * D / 4), c4 = i - r * (3 * D / 4);
                 v4f v = v4f{0.f, 0.f, 0.f, 0.f};
