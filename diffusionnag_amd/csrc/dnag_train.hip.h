@@ -1239,10 +1239,28 @@ __global__ void dropout_fill_kernel(uint8_t *keep, size_t n, float p, uint64_t s
 // partial[b] = sum of squares of the b-th contiguous chunk, accumulated in double in a fixed order
 __global__ __launch_bounds__(256) void optim_sumsq_kernel(const float *__restrict__ g, size_t n, double *__restrict__ partial) {
     __shared__ double sh[256];
-    const size_t chunk = (n + OPTIM_BLOCKS - 1) / OPTIM_BLOCKS;
-    const size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const size_t chunk = ((n + OPTIM_BLOCKS - 1) / OPTIM_BLOCKS + 1023) / 1024 * 1024;
+    const size_t lo = (size_t)blockIdx.x * chunk < n ? (size_t)blockIdx.x * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
     double acc = 0.0;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)g[i] * (double)g[i];
+    if (chunk % 1024 == 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+        // 16-byte loads, four passes (four independent sums) in flight; a block's range is whole passes of 1024 values
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        size_t i = lo + 4 * (size_t)threadIdx.x;
+        for (; i + 3 * 1024 + 4 <= hi; i += 4 * 1024) {
+            v4f v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const v4f *>(g + i + 1024 * u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                a4[u] += ((double)v[u].x * (double)v[u].x + (double)v[u].y * (double)v[u].y) +
+                         ((double)v[u].z * (double)v[u].z + (double)v[u].w * (double)v[u].w);
+        }
+        for (; i < hi; i += 1024)
+            for (int e = 0; e < 4 && i + e < hi; ++e) a4[0] += (double)g[i + e] * (double)g[i + e];
+        acc = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    } else {
+        for (size_t i = lo + threadIdx.x; i < hi; i += 256) acc += (double)g[i] * (double)g[i];
+    }
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int s2 = 128; s2 > 0; s2 >>= 1) {
