@@ -989,7 +989,7 @@ __global__ void put_labels_kernel(float *__restrict__ dst, const LabelChunk c, i
 // kernels' last rounds leave idle.  Results do not change (same kernels, disjoint workspace regions).  The first guided
 // call on a device creates the stream and its two events: make it outside a stream capture.
 // DNAG_OVERLAP=0 in the environment keeps everything on the caller's stream.
-struct SideStream { hipStream_t st; hipEvent_t fork, join; bool ok; std::mutex use; };
+struct SideStream { hipStream_t st; hipEvent_t fork, join, mid; bool ok; std::mutex use; };
 static SideStream g_side[64];
 static std::mutex g_side_mu;
 static int side_for_current_device(SideStream **out) {
@@ -1007,6 +1007,7 @@ static int side_for_current_device(SideStream **out) {
         HIP_TRY(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, hi));
         HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.mid, hipEventDisableTiming));
         s.ok = true;
     }
     *out = &s;
@@ -1444,22 +1445,29 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     hipLaunchKernelGGL(dsm_loss_kernel, dim3(TRAIN_LOSS_BLOCKS), dim3(256), 0, st, ws + w.out, p->z, p->std, p->score_mode, p->reduce_mean ? 1 : 0, B,
                        N * V, rows_pad * V, ws + w.dout, ws + w.lossp);
     LAUNCH_CHECK();
-    {
+    // the loss itself feeds nothing: with gradients its one-workgroup sum runs on the second stream (after the first fork)
+    auto loss_sum = [&](hipStream_t s_) -> int {
         const float scale = p->reduce_mean ? 1.0f / ((float)(N * V) * (float)B) : 0.5f / (float)B;
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(256), 0, st, ws + w.lossp, TRAIN_LOSS_BLOCKS, (size_t)1, (size_t)1, p->loss, scale);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(1), dim3(256), 0, s_, ws + w.lossp, TRAIN_LOSS_BLOCKS, (size_t)1, (size_t)1, p->loss, scale);
         LAUNCH_CHECK();
-    }
-    if (!p->grads) return 0;
+        return 0;
+    };
+    if (!p->grads) return loss_sum(st);
     float *G = p->grads;
     float *scr = ws + w.scratch;
     // The head's weight and bias gradients hang off the chain dout -> dH2 -> dH1 -> dconcat -> encoder backward without
-    // feeding it: they run on the second stream, forked where their operands are complete; the time-embedding gradients,
-    // which share their scratch, follow them on that stream (section 6) and the step ends with the join.
+    // feeding it: they run on the second stream, forked where their operands are complete, and the step ends with the join.
+    // The encoder backward leaves no CU to anything else (one workgroup per CU, and no GEMM tile fits beside it), so what
+    // the second stream still holds when it starts (most of dW1) runs after it, beside the HBM-bound slab reduction; the
+    // time-embedding gradients (a string of short kernels) go in front of that reduction on the main chain, where dW1's
+    // GEMM fills the chip around them (behind the reduction: 517 -> 505 steps/s; on the second stream behind dW1: 512).
+    // They share `scr` with the head's column sums: ordered by the `mid` event.
     // ---- 4. head backward ------------------------------------------------------------------------------------------
     hipLaunchKernelGGL((head_out_bwd_kernel<7>), dim3((unsigned)(rows_pad < 2048 ? rows_pad : 2048)), dim3(256), 0, st, ws + w.h2, ws + w.dout,
                        P + e.f2_w, Hd, rows, rows_pad, ws + w.dh2, amax_dh2);
     LAUNCH_CHECK();
     if (int rc = fork()) return rc;            // dout, dH2 and its scale are complete
+    if (int rc = loss_sum(sw)) return rc;
     if (int rc = launch_tn_small<0>(ws + w.dout, V, ws + w.h2, Hd, rows, w.nz_rows, V, Hd, scr, G + sl.f2_w, sw)) return rc;     // dW3 = dout^T H2
     if (int rc = launch_colsum(ws + w.dout, V, rows, w.nz_rows, V, scr, G + sl.f2_b, sw)) return rc;
     if (int rc = launch_colsum(ws + w.dh2, Hd, rows, w.nz_rows, Hd, scr, G + sl.f1_b, sw)) return rc;
@@ -1484,6 +1492,7 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     LAUNCH_CHECK();
     if (int rc = fork()) return rc;            // dH1 and its scale are complete
     if (int rc = launch_colsum(ws + w.dh1, Hd, rows, w.nz_rows, Hd, scr, G + sl.f0_b, sw)) return rc;
+    if (side) HIP_TRY(hipEventRecord(side->mid, side->st));            // the second stream's last use of scr
     if (int rc = launch_transpose(ws + w.dh1, rows_pad, Hd, Hd, ws + w.T1, rows_pad, rows_pad, sw)) return rc;
     if (int rc = launch_transpose(ws + w.concat, rows_pad, F, F, ws + w.T2, rows_pad, rows_pad, sw)) return rc;
     if (int rc = wgrad_gemm(ws + w.T1, amax_dh1, ws + w.T2, amax_cc, Hd, F, G + sl.f0_w)) return rc;     // dW1 = dH1^T concat
@@ -1492,7 +1501,15 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (int rc = train_g(B) == 8 ? launch_train_enc_bwd<8>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st)
                                  : launch_train_enc_bwd<4>(w.nblk_enc, P, tl, sv, ws + w.xt, ws + w.dconcat, p->mask, p->mask_stride ? 1 : 0, dm, ws + w.part, gl, ws + w.dtau, B, st))
         return rc;
-    if (int rc = fork()) return rc;            // dtau is complete: section 6 goes to the second stream, behind the head's gradients
+    // ---- 6. time-embedding MLP backward ---------------------------------------------------------------------------------
+    if (side) HIP_TRY(hipStreamWaitEvent(st, side->mid, 0));
+    hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(B), dim3(256), (size_t)d * sizeof(float), st, ws + w.dtau, ws + w.save_pre, d, P + e.t2_w, ws + w.dpre);
+    LAUNCH_CHECK();
+    if (int rc = launch_tn_small<1>(ws + w.dtau, d, ws + w.save_pre, 4 * d, B, w.nz_b, d, 4 * d, scr, G + sl.t2_w, st)) return rc;   // dW2 = dtau^T silu(pre)
+    if (int rc = launch_colsum(ws + w.dtau, d, B, w.nz_b, d, scr, G + sl.t2_b, st)) return rc;
+    if (int rc = launch_tn_small<0>(ws + w.dpre, 4 * d, ws + w.save_e, d, B, w.nz_b, 4 * d, d, scr, G + sl.t1_w, st)) return rc;    // dW1 = dpre^T e
+    if (int rc = launch_colsum(ws + w.dpre, 4 * d, B, w.nz_b, 4 * d, scr, G + sl.t1_b, st)) return rc;
+    // ---- 7. the encoder's weight gradients: slabs -> sums -> state order ---------------------------------------------------
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)((gl.total + 255) / 256)), dim3(256), 0, st, ws + w.part, w.nblk_enc, gl.total, gl.total,
                        ws + w.gsum, 1.0f);
     LAUNCH_CHECK();
@@ -1506,13 +1523,6 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
         hipLaunchKernelGGL(copy_segs_kernel, dim3(2), dim3(256), 0, st, gs);
         LAUNCH_CHECK();
     }
-    // ---- 6. time-embedding MLP backward (second stream: beside the reduction of the encoder's partial gradients) --------
-    hipLaunchKernelGGL(time_embed_bwd_kernel, dim3(B), dim3(256), (size_t)d * sizeof(float), sw, ws + w.dtau, ws + w.save_pre, d, P + e.t2_w, ws + w.dpre);
-    LAUNCH_CHECK();
-    if (int rc = launch_tn_small<1>(ws + w.dtau, d, ws + w.save_pre, 4 * d, B, w.nz_b, d, 4 * d, scr, G + sl.t2_w, sw)) return rc;   // dW2 = dtau^T silu(pre)
-    if (int rc = launch_colsum(ws + w.dtau, d, B, w.nz_b, d, scr, G + sl.t2_b, sw)) return rc;
-    if (int rc = launch_tn_small<0>(ws + w.dpre, 4 * d, ws + w.save_e, d, B, w.nz_b, 4 * d, d, scr, G + sl.t1_w, sw)) return rc;    // dW1 = dpre^T e
-    if (int rc = launch_colsum(ws + w.dpre, 4 * d, B, w.nz_b, 4 * d, scr, G + sl.t1_b, sw)) return rc;
     return join();
 }
 
