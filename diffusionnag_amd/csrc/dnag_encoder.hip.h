@@ -253,6 +253,7 @@ struct EncGeom {
 struct EncSave {
     float *h, *h1, *qkv, *f;
     size_t rows;
+    float *amax_concat;     // optional (encoder8_kernel, training modes): max |concat| as float bits, atomicMax; the caller clears it
 };
 
 // Dropout keep masks of a training-mode forward (models/cate.py:147, transformer.py:19, :54, :80, :108):

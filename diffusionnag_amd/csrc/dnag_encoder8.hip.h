@@ -248,6 +248,7 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void encoder8_kernel(const 
     // LN(h) * 16 of the wave's registers as split-pair quads into A16.  These rows are both the next layer's QKV operand
     // and -- the affine of the output norm being folded into final.linears.0 (CateLayout::f0_s) -- the concat slice of
     // the layer that just ended, which concat_out copies to HBM.
+    float cmax = 0.f;            // SAVE modes: largest |concat| value this lane wrote (sv.amax_concat)
     auto norm_write = [&](int r, int h, int lc) {
         float mean, rstd;
         stats_get(r, mean, rstd);
@@ -262,7 +263,10 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void encoder8_kernel(const 
                     v4f o4;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o4[e] = (hacc[4 * gq + e] - mean) * rstd * g4[e] + b4[e];
-                    if (live(row)) *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + row) * lay.F + (size_t)lc * D + c0) = o4;
+                    if (live(row)) {
+                        *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + row) * lay.F + (size_t)lc * D + c0) = o4;
+                        cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(o4[0]), fabsf(o4[1]))), fmaxf(fabsf(o4[2]), fabsf(o4[3])));
+                    }
                 }
             }
         }
@@ -816,6 +820,15 @@ __global__ __launch_bounds__(256, MODE == 0 ? 2 : 1) void encoder8_kernel(const 
             }
             stats_put(r, h);
             E8_SUB();
+        }
+    }
+    if constexpr (SAVE) {
+        if (sv.amax_concat != nullptr) {
+            cmax = fmaxf(cmax, dpp_mov<0xB1>(cmax));
+            cmax = fmaxf(cmax, dpp_mov<0x4E>(cmax));
+            cmax = fmaxf(cmax, dpp_mov<0x141>(cmax));
+            cmax = fmaxf(cmax, dpp_mov<0x140>(cmax));      // every lane: the maximum of its row of 16
+            if ((tid & 15) == 0) atomicMax(reinterpret_cast<unsigned int *>(sv.amax_concat), __float_as_uint(cmax));
         }
     }
 #ifdef ENC8_STAMPS

@@ -875,7 +875,7 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
     const CateLayout &e = y.enc;
     const int F = e.F, Hd = e.Hd;
     EncSave sv;
-    sv.h = ws + w.sv_h; sv.h1 = ws + w.sv_h1; sv.qkv = ws + w.sv_qkv; sv.f = ws + w.sv_f; sv.rows = w.rows_pad;
+    sv.h = ws + w.sv_h; sv.h1 = ws + w.sv_h1; sv.qkv = ws + w.sv_qkv; sv.f = ws + w.sv_f; sv.rows = w.rows_pad; sv.amax_concat = nullptr;
     {   // encoder, saving what the backward pass needs
         typedef EncGeom<PC_N, PC_G, 32> Ge;
         const size_t lds = Ge::lds_floats * sizeof(float);
@@ -1421,6 +1421,7 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     // ---- 2. encoder forward, saving the activations the backward pass needs -------------------------------------
     EncSave sv;
     sv.h = ws + w.sv_h; sv.h1 = ws + w.sv_h1; sv.qkv = ws + w.sv_qkv; sv.f = ws + w.sv_f; sv.rows = rows_pad;
+    sv.amax_concat = amax_cc;          // max |concat| for the head GEMMs' operand scale, taken where the concat is written
     DropMasks dm;
     memset(&dm, 0, sizeof(dm));
     if (drop) { dm.keep = p->keep; dm.keep_prob = 1.0f - p->dropout_p; dm.rows = rows; dm.per_layer = cd.n_head * N + 2 * d + dff; }
@@ -1428,8 +1429,6 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
         return rc;
     // ---- 3. head MLP and loss ------------------------------------------------------------------------------------
     // all six big GEMMs of the step run on the split-arithmetic fp16 MFMA kernel with fp32 operands split on the fly
-    hipLaunchKernelGGL(amax_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, rows * (size_t)F, amax_cc);
-    LAUNCH_CHECK();
     if (int rc = join()) return rc;            // the weights' scales (and transposes)
     if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.concat, F, amax_cc, P + e.f0_w, F, amax_w0, P + e.f0_b, ws + w.h1, Hd, nullptr, rows_pad, Hd, F, 1, st, amax_h1)) return rc;
     if (int rc = launch_gemm32<ACT_ELU, 3>(ws + w.h1, Hd, amax_h1, P + e.f1_w, Hd, amax_w1, P + e.f1_b, ws + w.h2, Hd, nullptr, rows_pad, Hd, Hd, 1, st)) return rc;
