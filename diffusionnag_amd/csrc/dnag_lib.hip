@@ -1401,15 +1401,7 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 8 * sizeof(float), st));
     float *amax_dh2 = ws + w.amax, *amax_dh1 = ws + w.amax + 1, *amax_w0 = ws + w.amax + 2, *amax_w1 = ws + w.amax + 3;
     float *amax_cc = ws + w.amax + 4, *amax_h1 = ws + w.amax + 5;
-    if (int rc = fork()) return rc;            // the packed head weights and the cleared scales are in place
-    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, sw, P + e.f0_w, (size_t)Hd * F, amax_w0);
-    LAUNCH_CHECK();
-    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, sw, P + e.f1_w, (size_t)Hd * Hd, amax_w1);
-    LAUNCH_CHECK();
-    if (p->grads) {
-        if (int rc = launch_transpose(S + sl.f0_w, Hd, F, F, P + tl.f0T, Hd, Hd, sw)) return rc;      // [Hd][F] -> [F][Hd]
-        if (int rc = launch_transpose(S + sl.f1_w, Hd, Hd, Hd, P + tl.f1T, Hd, Hd, sw)) return rc;
-    }
+    if (side) HIP_TRY(hipEventRecord(side->fork, st));      // the packed head weights and the cleared scales are in place
     // ---- 1. time embedding per graph, perturbation -----------------------------------------------------------
     hipLaunchKernelGGL(time_embed_train_kernel, dim3(B), dim3(256), (size_t)5 * d * sizeof(float), st, p->labels, d, P + e.freq, P + e.t1_w,
                        P + e.t1_b, P + e.t2_w, P + e.t2_b, ws + w.temb, ws + w.save_e, ws + w.save_pre);
@@ -1427,6 +1419,17 @@ extern "C" int dnag_cate_dsm_step(const dnag_train_args *p) {
     if (drop) { dm.keep = p->keep; dm.keep_prob = 1.0f - p->dropout_p; dm.rows = rows; dm.per_layer = cd.n_head * N + 2 * d + dff; }
     if (int rc = launch_train_encoder<8>(drop, (B + 7) / 8, P, e, ws + w.xt, ws + w.temb, p->mask, p->mask_stride ? 1 : 0, ws + w.concat, B, sv, dm, st))
         return rc;
+    // (the event was recorded in front of section 1; the wait and these launches are enqueued behind the encoder's launch:
+    // enqueued in front of it, the main stream's next kernel started only after they had run)
+    if (side) HIP_TRY(hipStreamWaitEvent(side->st, side->fork, 0));
+    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, sw, P + e.f0_w, (size_t)Hd * F, amax_w0);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(amax_kernel, dim3(256), dim3(256), 0, sw, P + e.f1_w, (size_t)Hd * Hd, amax_w1);
+    LAUNCH_CHECK();
+    if (p->grads) {
+        if (int rc = launch_transpose(S + sl.f0_w, Hd, F, F, P + tl.f0T, Hd, Hd, sw)) return rc;      // [Hd][F] -> [F][Hd]
+        if (int rc = launch_transpose(S + sl.f1_w, Hd, Hd, Hd, P + tl.f1T, Hd, Hd, sw)) return rc;
+    }
     // ---- 3. head MLP and loss ------------------------------------------------------------------------------------
     // all six big GEMMs of the step run on the split-arithmetic fp16 MFMA kernel with fp32 operands split on the fly
     if (int rc = join()) return rc;            // the weights' scales (and transposes)
