@@ -253,7 +253,7 @@ struct EncGeom {
 struct EncSave {
     float *h, *h1, *qkv, *f;
     size_t rows;
-    float *amax_concat;     // optional (encoder8_kernel, training modes): max |concat| as float bits, atomicMax; the caller clears it
+    float *amax_concat;     // optional (encoder8_kernel's training modes, encoder_kernel with SAVE and fp32 concat rows): max |concat| as float bits, atomicMax; the caller clears it
 };
 
 // Dropout keep masks of a training-mode forward (models/cate.py:147, transformer.py:19, :54, :80, :108):
@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
     const int g0 = blockIdx.x * G;
     const int L = lay.L;
     const float sa_concat = SPLIT ? P[lay.hsc + HEAD_SC_SA_CONCAT] : 0.f;
+    float cmax = 0.f;            // SAVE: largest |concat| value this lane wrote (EncSave::amax_concat)
     const size_t rows_pad = ((size_t)batch * N + 255) / 256 * 256;      // SPLIT: the concat is k-tile blocked (dnag_gemm16.hip.h kblock_at)
 #ifdef DNAG_ENC_STAMPS
     long long ts_[96];
@@ -602,13 +603,24 @@ __global__ __launch_bounds__(256, 2) void encoder_kernel(const float *__restrict
                         _Float16 *dst = reinterpret_cast<_Float16 *>(concat) + kblock_half_at((size_t)g0 * N + r, (k >> 3) * 16 + (k & 7), rows_pad);
                         *reinterpret_cast<h4_t *>(dst) = hi4;
                         *reinterpret_cast<h4_t *>(dst + 8) = lo4;
-                    } else
-                    *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + r) * lay.F + l * D + 4 * sub) = o4;
+                    } else {
+                        *reinterpret_cast<v4f *>(concat + ((size_t)g0 * N + r) * lay.F + l * D + 4 * sub) = o4;
+                        if constexpr (SAVE) cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(o4.x), fabsf(o4.y))), fmaxf(fabsf(o4.z), fabsf(o4.w)));
+                    }
                 }
             }
         }
         ENC_STAMP();
         // no barrier needed: the next phase only reads hbuf and writes qkv
+    }
+    if constexpr (SAVE && !SPLIT) {
+        if (sv.amax_concat != nullptr) {             // max |concat| of the rows this workgroup wrote (a later GEMM's operand scale)
+            cmax = fmaxf(cmax, dpp_mov<0xB1>(cmax));
+            cmax = fmaxf(cmax, dpp_mov<0x4E>(cmax));
+            cmax = fmaxf(cmax, dpp_mov<0x141>(cmax));
+            cmax = fmaxf(cmax, dpp_mov<0x140>(cmax));
+            if ((tid & 15) == 0) atomicMax(reinterpret_cast<unsigned int *>(sv.amax_concat), __float_as_uint(cmax));
+        }
     }
 #ifdef DNAG_ENC_STAMPS
     if (blockIdx.x == 5 && tid == 0) for (int i = 1; i < nts_; ++i) printf("enc %d %lld\n", i, ts_[i] - ts_[i - 1]);

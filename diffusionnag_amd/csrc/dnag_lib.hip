@@ -866,6 +866,13 @@ static int predcate_prepare(const PredCateLayout &y, const float *P, const float
                        ws + w.beff);
     LAUNCH_CHECK();
     HIP_TRY(hipMemsetAsync(ws + w.flat, 0, w.bpad * y.RK * sizeof(float), st));
+    // operand scales of the two final-MLP weight matrices: constants of the call (slots 0, 1 of amax; run_predcate clears 2..7)
+    const CateLayout &e = y.enc;
+    HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 2 * sizeof(float), st));
+    hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, P + e.f0_w, (size_t)e.Hd * e.F, ws + w.amax);
+    LAUNCH_CHECK();
+    hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, P + e.f1_w, (size_t)e.Hd * e.Hd, ws + w.amax + 1);
+    LAUNCH_CHECK();
     return 0;
 }
 
@@ -875,7 +882,10 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
     const CateLayout &e = y.enc;
     const int F = e.F, Hd = e.Hd;
     EncSave sv;
-    sv.h = ws + w.sv_h; sv.h1 = ws + w.sv_h1; sv.qkv = ws + w.sv_qkv; sv.f = ws + w.sv_f; sv.rows = w.rows_pad; sv.amax_concat = nullptr;
+    sv.h = ws + w.sv_h; sv.h1 = ws + w.sv_h1; sv.qkv = ws + w.sv_qkv; sv.f = ws + w.sv_f; sv.rows = w.rows_pad;
+    const bool split_ok = e.Hd % SplitGeom::BN == 0 && e.F % GEMM_BK == 0;
+    sv.amax_concat = split_ok ? ws + w.amax + 2 : nullptr;      // the encoder leaves max |concat| there (operand scale of the first GEMM)
+    if (split_ok) HIP_TRY(hipMemsetAsync(ws + w.amax + 2, 0, 6 * sizeof(float), st));      // slots 0, 1: predcate_prepare
     {   // encoder, saving what the backward pass needs
         typedef EncGeom<PC_N, PC_G, 32> Ge;
         const size_t lds = Ge::lds_floats * sizeof(float);
@@ -894,16 +904,8 @@ static int run_predcate(const PredCateLayout &y, const float *P, const float *x,
     // the device (amax_kernel, or the producing GEMM's epilogue), as in the training step.  Nout = Hd = 256 is one tile
     // column of that kernel; the GEMMs with 128 or 384 output columns stay on the fp32 MFMA kernel.
     float *amax_w0 = ws + w.amax, *amax_w1 = ws + w.amax + 1, *amax_cc = ws + w.amax + 2, *amax_h1 = ws + w.amax + 3, *amax_dh2 = ws + w.amax + 4;
-    const bool split_ok = Hd % SplitGeom::BN == 0 && F % GEMM_BK == 0;
     if (split_ok) {
-        HIP_TRY(hipMemsetAsync(ws + w.amax, 0, 8 * sizeof(float), st));
         if (w.rows_pad > w.rows) HIP_TRY(hipMemsetAsync(ws + w.concat + w.rows * F, 0, (w.rows_pad - w.rows) * F * sizeof(float), st));
-        hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, P + e.f0_w, (size_t)Hd * F, amax_w0);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(amax_kernel, dim3(64), dim3(256), 0, st, P + e.f1_w, (size_t)Hd * Hd, amax_w1);
-        LAUNCH_CHECK();
-        hipLaunchKernelGGL(amax_kernel, dim3(1024), dim3(256), 0, st, ws + w.concat, w.rows * (size_t)F, amax_cc);
-        LAUNCH_CHECK();
         if (int rc = launch_gemm32<ACT_ELU, 5>(ws + w.concat, F, amax_cc, P + e.f0_w, F, amax_w0, P + e.f0_b, ws + w.h1, Hd, nullptr, w.rows_pad, Hd, F, 1, st, amax_h1)) return rc;
         if (int rc = launch_gemm32<ACT_ELU, 5>(ws + w.h1, Hd, amax_h1, P + e.f1_w, Hd, amax_w1, P + e.f1_b, ws + w.h2, Hd, nullptr, w.rows_pad, Hd, Hd, 1, st)) return rc;
     } else {
