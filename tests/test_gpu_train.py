@@ -278,3 +278,26 @@ def test_second_stream_changes_no_gradient_bit(monkeypatch):
     for a in two[1:]:
         for ga, gb in zip(a[1:], two[0][1:]):
             assert torch.equal(ga, gb)
+
+
+def test_sampler_and_training_step_share_the_second_stream():
+    """dnag_pc_sample and dnag_cate_dsm_step use the same library-owned stream per device: a trajectory, a training
+    step and the trajectory again, back to back on one caller stream -- the two trajectories are equal to the bit and
+    the step's gradients equal those of a step taken alone."""
+    from tests.test_gpu_parity import run_sampler
+    g = golden("train_nb201_vp_drop")
+    x, t, z, dropout = train_case(g)
+    sde = sde_lib.VPSDE(0.1, 20.0, 1000)
+    maskB = torch.from_numpy(g["mask"]).unsqueeze(0).repeat(x.shape[0], 1, 1)
+    gs = golden("pc_guided_nb201_n1000_first8")
+    model = make_model(0)
+    run_step(model, sde, x, t, z, maskB, dropout)
+    alone = [p.grad.detach().clone() for p in model.parameters()]
+    f1, _ = run_sampler(gs, True, record=False)
+    model2 = make_model(0)
+    run_step(model2, sde, x, t, z, maskB, dropout)
+    f2, _ = run_sampler(gs, True, record=False)
+    host = lambda v: v.detach().cpu() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))
+    assert torch.equal(host(f1), host(f2))
+    for a, p in zip(alone, model2.parameters()):
+        assert torch.equal(a, p.grad)
