@@ -1007,9 +1007,11 @@ static int side_for_current_device(SideStream **out) {
         int lo = 0, hi = 0;
         HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIP_TRY(hipStreamCreateWithPriority(&s.st, hipStreamNonBlocking, hi));
-        HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&s.mid, hipEventDisableTiming));
+        // no system-scope fence at the events: both streams are on this device (a record costs 4.8 instead of 6.4 us on the
+        // recording stream; NB201 2794 -> 2809 samples/s same box)
+        HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming | hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming | hipEventDisableSystemFence));
+        HIP_TRY(hipEventCreateWithFlags(&s.mid, hipEventDisableTiming | hipEventDisableSystemFence));
         s.ok = true;
     }
     *out = &s;
